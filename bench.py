@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X attention hot path on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (N=1): Qwen3-0.6B shapes (L=28, H_q=16, H_kv=8, D=128, hidden 1024), decode batch 256,
+context lengths ragged U[513,768] (the 512-in/256-out run's range), KV block 256, bf16,
+synthetic random data, shuffled physical blocks.  One STEP = one decode step of the hot path
+over all 28 layers: per layer two residual-add RMSNorms at hidden size, the fused q/k-norm +
+rotary + KV-cache scatter, and paged decode attention.  Inputs are resident in HBM before the
+timed region.
+
+`value` = algorithmic HBM bytes of the whole step / wall time of the step (GB/s).
+`roofline` is for the dominant kernel (paged decode attention): algorithmic bytes per launch
+(4096 B per cached token + 8 KiB of Q/O + table bytes, summed over the batch) divided by the
+average launch duration measured with HIP events on the launch stream inside the timed steps.
+`cpu_baseline` times the CPU oracle (torch, fp32) of the same attention on a bounded sample
+on the host cores (rank 0, N=1 only).
+
+N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs an independent
+replica of the same batch (data-parallel replicas, no data-path collective; weak scaling);
+the time is the max over ranks between two barriers.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--ctx-lo", type=int, default=513)
+    ap.add_argument("--ctx-hi", type=int, default=768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--attn-only", action="store_true", help="step = decode attention launches only")
+    return ap.parse_args()
+
+
+class Workload:
+    """Qwen3-0.6B-shaped decode step; everything lives on `dev`."""
+
+    H_Q, H_KV, D, HIDDEN, BS = 16, 8, 128, 1024, 256
+    EPS, MAX_POS, ROPE_BASE = 1e-6, 40960, 1e6
+
+    def __init__(self, dev, layers, batch, lo, hi, seed=0):
+        from nanovllm_amd.layers.rope import build_cos_sin_cache
+        self.dev, self.L, self.B = dev, layers, batch
+        g = torch.Generator().manual_seed(seed)
+        self.ctx = torch.randint(lo, hi + 1, (batch,), generator=g).tolist()
+        blocks = [math.ceil(c / self.BS) for c in self.ctx]
+        self.NB = sum(blocks)
+        perm = torch.randperm(self.NB, generator=g).tolist()
+        width = max(blocks)
+        tables, nxt = [], 0
+        for nb in blocks:
+            tables.append(perm[nxt:nxt + nb] + [-1] * (width - nb))
+            nxt += nb
+        self.block_tables = torch.tensor(tables, dtype=torch.int32, device=dev)
+        self.cu_k = torch.tensor([0] + torch.tensor(self.ctx).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+        self.cu_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
+        self.max_k = max(self.ctx)
+        # the new token of sequence b sits at position ctx-1
+        self.positions = torch.tensor([c - 1 for c in self.ctx], dtype=torch.int64, device=dev)
+        self.slots = torch.tensor([tables[b][(c - 1) // self.BS] * self.BS + (c - 1) % self.BS
+                                   for b, c in enumerate(self.ctx)], dtype=torch.int32, device=dev)
+        # [2, L, NB, bs, H_kv, D] as the reference's runner allocates it, filled with N(0,1)
+        self.kv_cache = torch.empty(2, layers, self.NB, self.BS, self.H_KV, self.D, dtype=torch.bfloat16, device=dev)
+        for l in range(layers):
+            self.kv_cache[0, l].normal_()
+            self.kv_cache[1, l].normal_()
+        gen = torch.Generator(device=dev).manual_seed(seed)
+        qkv_w = (self.H_Q + 2 * self.H_KV) * self.D
+        self.qkv = torch.randn(batch, qkv_w, generator=gen, device=dev).bfloat16()
+        self.q_in = self.qkv[:, :self.H_Q * self.D].view(batch, self.H_Q, self.D)
+        self.k_in = self.qkv[:, self.H_Q * self.D:(self.H_Q + self.H_KV) * self.D].view(batch, self.H_KV, self.D)
+        self.v_in = self.qkv[:, (self.H_Q + self.H_KV) * self.D:].view(batch, self.H_KV, self.D)
+        self.q_w = (1 + 0.1 * torch.randn(self.D, generator=gen, device=dev)).bfloat16()
+        self.k_w = (1 + 0.1 * torch.randn(self.D, generator=gen, device=dev)).bfloat16()
+        self.h_w = (1 + 0.1 * torch.randn(self.HIDDEN, generator=gen, device=dev)).bfloat16()
+        self.hidden = torch.randn(batch, self.HIDDEN, generator=gen, device=dev).bfloat16()
+        self.resid = torch.randn(batch, self.HIDDEN, generator=gen, device=dev).bfloat16()
+        self.cos_sin = build_cos_sin_cache(self.D, self.MAX_POS, self.ROPE_BASE).to(dev).view(self.MAX_POS, self.D)
+        self.scale = self.D ** -0.5
+        # preallocated outputs (the timed region allocates nothing)
+        self.q_rot = torch.empty(batch, self.H_Q, self.D, dtype=torch.bfloat16, device=dev)
+        self.o = torch.empty(batch, self.H_Q, self.D, dtype=torch.bfloat16, device=dev)
+        self.y = torch.empty_like(self.hidden)
+        self.new_res = torch.empty_like(self.hidden)
+
+    # ---- algorithmic bytes -------------------------------------------------------------
+    def attn_bytes_per_launch(self):
+        return sum(2 * c * self.H_KV * self.D * 2 + 2 * self.H_Q * self.D * 2 + 4 * math.ceil(c / self.BS) + 8
+                   for c in self.ctx)
+
+    def step_bytes(self, attn_only=False):
+        a = self.attn_bytes_per_launch()
+        if attn_only:
+            return a * self.L
+        T = self.B
+        heads = self.H_Q + 2 * self.H_KV
+        fused = 2 * T * heads * self.D * 2 + T * self.D * 4 + 12 * T        # in + out, cos/sin row, pos + slot
+        norm = T * self.HIDDEN * 2 * 4 + self.HIDDEN * 2                    # x, res in; y, new_res out; weight
+        return (a + fused + 2 * norm) * self.L
+
+    # ---- raw C-ABI launch plans (argument tuples prebuilt; nothing allocated per call) ---
+    def build_plan(self, attn_only=False):
+        from nanovllm_amd import _lib
+        dll = _lib.lib()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        ws_bytes = dll.nv_attn_decode_workspace_bytes(self.B, self.H_Q, self.H_KV, self.D, self.max_k)
+        self.ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+        plan = []          # (fn, args, is_attention)
+        for l in range(self.L):
+            kc, vc = self.kv_cache[0, l], self.kv_cache[1, l]
+            if not attn_only:
+                norm_args = (self.hidden.data_ptr(), self.resid.data_ptr(), self.h_w.data_ptr(), self.y.data_ptr(),
+                             self.new_res.data_ptr(), self.B, self.HIDDEN, self.EPS, stream)
+                plan.append((dll.nv_add_rmsnorm, norm_args, False))
+                plan.append((dll.nv_qknorm_rope_store,
+                             (self.q_in.data_ptr(), self.k_in.data_ptr(), self.v_in.data_ptr(), self.q_w.data_ptr(),
+                              self.k_w.data_ptr(), self.cos_sin.data_ptr(), self.positions.data_ptr(),
+                              self.slots.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.q_rot.data_ptr(), None,
+                              self.B, self.H_Q, self.H_KV, self.D, self.MAX_POS, self.EPS, self.NB, self.BS,
+                              self.q_in.stride(0), self.k_in.stride(0), self.v_in.stride(0), stream), False))
+            plan.append((dll.nv_attn_decode_paged,
+                         (self.q_rot.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.o.data_ptr(),
+                          self.cu_q.data_ptr(), self.cu_k.data_ptr(), self.block_tables.data_ptr(), self.B,
+                          self.block_tables.shape[1], self.max_k, self.H_Q, self.H_KV, self.D, self.NB, self.BS,
+                          self.scale, self.q_rot.stride(0), self.o.stride(0), self.ws.data_ptr(), self.ws.numel(),
+                          stream), True))
+            if not attn_only:
+                plan.append((dll.nv_add_rmsnorm, norm_args, False))
+        return plan
+
+
+def run_step(plan, events=None):
+    for fn, args, is_attn in plan:
+        if events is not None and is_attn:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args)
+            b.record()
+            events.append((a, b))
+        else:
+            rc = fn(*args)
+        if rc != 0:
+            from nanovllm_amd import _lib
+            _lib.check(rc, fn.__name__)
+
+
+def cpu_baseline(w: Workload, seconds: float):
+    """The CPU oracle on one layer's cache, sequence by sequence, for about `seconds`."""
+    from oracle.ref_attention import paged_attention_ref
+    threads = torch.get_num_threads()
+    kc, vc = w.kv_cache[0, 0].cpu(), w.kv_cache[1, 0].cpu()
+    q = torch.randn(w.B, w.H_Q, w.D).bfloat16()
+    bt, ctx = w.block_tables.cpu(), w.ctx
+    done_bytes, done_seqs = 0, 0
+    t0 = time.perf_counter()
+    b = 0
+    while time.perf_counter() - t0 < seconds and done_seqs < 4 * w.B:
+        i = b % w.B
+        paged_attention_ref(q[i:i + 1], kc, vc, torch.tensor([0, 1], dtype=torch.int32),
+                            torch.tensor([0, ctx[i]], dtype=torch.int32), bt[i:i + 1], w.scale)
+        done_bytes += 2 * ctx[i] * w.H_KV * w.D * 2 + 2 * w.H_Q * w.D * 2 + 4 * math.ceil(ctx[i] / w.BS) + 8
+        done_seqs += 1
+        b += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(done_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"oracle decode attention, 1 layer, {done_seqs} sequences of the same batch "
+                      f"(ctx {min(ctx)}..{max(ctx)}), {dt:.1f} s, torch fp32 on {threads} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w = Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi, seed=rank)
+    plan = w.build_plan(args.attn_only)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        run_step(plan)
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(plan, events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        tot = torch.tensor([float(w.step_bytes(args.attn_only))], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        step_bytes_all = tot.item()
+    else:
+        step_bytes_all = float(w.step_bytes(args.attn_only))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = step_bytes_all / (elapsed / args.steps) / 1e9
+    attn_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+    achieved = w.attn_bytes_per_launch() / (attn_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "decode_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "paged-decode attn HBM GB/s", "value": round(value, 1), "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Qwen3-0.6B shapes, decode batch {args.batch}, ctx U[{args.ctx_lo},{args.ctx_hi}], "
+                                   f"block 256, {args.layers} layers; step = "
+                                   + ("decode attention only" if args.attn_only else
+                                      "2x add+RMSNorm, fused qk-norm+RoPE+KV store, paged decode attention per layer"),
+                       "H_q": 16, "H_kv": 8, "head_dim": 128, "batch": args.batch, "layers": args.layers,
+                       "parallelism": "single GPU" if world == 1 else f"dp{world} replicas"},
+            "pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
+            "hot_path_tok_per_s": round(args.batch * world / (ms_per_step * 1e-3), 1),
+            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (+merge)", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "launch_ms": round(attn_ms, 5),
+                         "algorithmic_bytes_per_launch": w.attn_bytes_per_launch()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/*
+ * nanovllm_hip.h — C ABI of the gfx950 (MI355X) attention hot path.
+ *
+ * Every entry point
+ *   - takes raw DEVICE pointers, plain sizes/strides and a HIP stream (passed as void*,
+ *     i.e. a hipStream_t; NULL = the default stream),
+ *   - only enqueues work on that stream: it never synchronises and, unless stated
+ *     otherwise, never allocates,
+ *   - returns NV_OK (0) or a negative NV_ERR_* code; nv_strerror() names the code and
+ *     nv_last_error() gives the detail message of the calling thread's last failure.
+ *
+ * Data types are fixed: activations and KV cache are bf16 (passed as void*), metadata is
+ * int32 except `positions` (int64), the rotary table is fp32.  head_dim must be 128.
+ *
+ * The reference (pradsgit/nano-vllm) has no FFI layer: the functions below replace the
+ * device work its three layer modules hand to flash-attn / ATen / Inductor.  Each
+ * declaration cites the reference lines it stands in for (paths relative to the
+ * reference checkout).
+ */
+#ifndef NANOVLLM_HIP_H
+#define NANOVLLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported symbol marker (the library is built with hidden default visibility) */
+#define NV_API __attribute__((visibility("default")))
+
+#define NV_OK 0
+#define NV_ERR_INVALID_ARG (-1)   /* null pointer, negative size, unsupported head_dim ... */
+#define NV_ERR_UNSUPPORTED (-2)   /* a shape the kernels are not built for               */
+#define NV_ERR_WORKSPACE (-3)     /* workspace missing or smaller than required           */
+#define NV_ERR_LAUNCH (-4)        /* hipLaunchKernel / hipGetLastError reported a failure */
+
+NV_API const char* nv_strerror(int code);
+NV_API const char* nv_last_error(void);
+/* ABI version of this library (bumped on any signature change). */
+NV_API int nv_abi_version(void);
+
+/*
+ * KV-cache scatter.  Replaces Attention.store_kvcache, nanovllm/layers/attention.py:210-219:
+ *   k_cache[slot // block_size, slot % block_size] = k[t]   (same for v)
+ * k, v: [T, H_kv, D] bf16, token stride given in ELEMENTS (rows themselves contiguous).
+ * k_cache, v_cache: [num_blocks, block_size, H_kv, D] bf16 contiguous.
+ * slot_mapping: [T] int32.  Slots < 0 or >= num_blocks*block_size are skipped (the
+ * reference never produces them on its live path; skipping keeps padding harmless).
+ * Bit-exact copy.
+ */
+NV_API int nv_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache,
+                     const int32_t* slot_mapping, int T, int H_kv, int D,
+                     int64_t num_blocks, int block_size,
+                     int64_t k_stride_t, int64_t v_stride_t, void* stream);
+
+/*
+ * Paged decode attention (every selected sequence has exactly one query token).
+ * Replaces the flash_attn_varlen_func call at nanovllm/layers/attention.py:241-252 for
+ * steps whose sequences all have seqlen_q == 1.
+ *   q: [T, H_q, D] bf16 (token stride q_stride_t elements); o: [T, H_q, D] bf16
+ *   (token stride o_stride_t elements).
+ *   cu_seqlens_k: [B+1] int32; sequence b attends to keys 0 .. cu_k[b+1]-cu_k[b]-1, key j
+ *   living at cache[block_tables[b, j / block_size], j % block_size, h_q / (H_q/H_kv)].
+ *   cu_seqlens_q: [B+1] int32 or NULL.  NULL means token b belongs to sequence b.  When
+ *   given, sequences with seqlen_q != 1 are skipped (they belong to the prefill kernel).
+ *   block_tables: [B, max_blocks] int32, padded with -1 (padding is never dereferenced).
+ *   max_seqlen_k: host-side upper bound of the per-sequence key count.
+ *   workspace: device scratch of at least nv_attn_decode_workspace_bytes(...) bytes,
+ *   16-byte aligned; contents need no initialisation.
+ * Sequences with zero keys produce zeros.
+ */
+NV_API int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k);
+NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* v_cache, void* o,
+                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                         const int32_t* block_tables, int B, int max_blocks,
+                         int max_seqlen_k, int H_q, int H_kv, int D,
+                         int64_t num_blocks, int block_size, float scale,
+                         int64_t q_stride_t, int64_t o_stride_t,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Varlen prefill / chunked-prefill attention over the paged cache, causal mask aligned
+ * to the bottom-right corner: query i of n_q sees keys j <= n_k - n_q + i.
+ * Replaces the same call (nanovllm/layers/attention.py:241-252) for steps with any
+ * seqlen_q > 1; argument wiring follows nanovllm/engine/model_runner.py:85-119.
+ *   cu_seqlens_q, cu_seqlens_k: [B+1] int32.  max_seqlen_q: host-side upper bound.
+ *   skip_single_query != 0 leaves sequences with seqlen_q == 1 untouched (the caller
+ *   runs nv_attn_decode_paged for them); 0 processes every sequence here.
+ * Rows with no visible key produce zeros.
+ */
+NV_API int nv_attn_prefill_varlen(const void* q, const void* k_cache, const void* v_cache, void* o,
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                           const int32_t* block_tables, int B, int max_blocks,
+                           int max_seqlen_q, int max_seqlen_k, int H_q, int H_kv, int D,
+                           int64_t num_blocks, int block_size, float scale,
+                           int64_t q_stride_t, int64_t o_stride_t,
+                           int skip_single_query, void* stream);
+
+/*
+ * RMSNorm.  Replaces RMSNorm.forward without residual, nanovllm/layers/layernorm.py:79-100:
+ *   y = bf16( f32(x) * rsqrt(mean(f32(x)^2) + eps) * f32(w) )
+ * x: [rows, cols] bf16 with row stride x_stride elements; y: [rows, cols] contiguous.
+ * cols must be a multiple of 8 and at most 16384.  Also used per head (cols = head_dim).
+ */
+NV_API int nv_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int cols,
+               int64_t x_stride, float eps, void* stream);
+
+/*
+ * Fused residual add + RMSNorm.  Replaces RMSNorm.forward with residual,
+ * nanovllm/layers/layernorm.py:88-100:
+ *   s = f32(x) + f32(res);  new_res = bf16(s);  y = bf16( s * rsqrt(mean(s^2)+eps) * f32(w) )
+ * (y is computed from the unrounded s).  All tensors [rows, cols] contiguous bf16.
+ * y may alias x and new_res may alias res.
+ */
+NV_API int nv_add_rmsnorm(const void* x, const void* res, const void* w, void* y, void* new_res,
+                   int64_t rows, int cols, float eps, void* stream);
+
+/*
+ * Rotary embedding (NeoX rotate-half), replaces RotaryPositionEmbedding.forward,
+ * nanovllm/layers/rope.py:45-56 with apply_rotary_emb :5-13:
+ *   cs = cos_sin[pos];  y = [x1*cos - x2*sin, x1*sin + x2*cos]  in fp32, cast to bf16.
+ * q: [T, H_q, D], k: [T, H_kv, D] bf16 (token strides in elements, heads contiguous);
+ * q_out, k_out contiguous.  cos_sin: [max_pos, D] fp32 (cos | sin).  positions: [T] int64.
+ * Positions outside [0, max_pos) are clamped into range.
+ */
+NV_API int nv_rope(const void* q, const void* k, void* q_out, void* k_out, const float* cos_sin,
+            const int64_t* positions, int T, int H_q, int H_kv, int D, int64_t max_pos,
+            int64_t q_stride_t, int64_t k_stride_t, void* stream);
+
+/*
+ * Fused per-head RMSNorm (q_norm / k_norm) + rotary embedding + KV-cache scatter: the
+ * chain nanovllm/model/qwen3.py:67-75 (q_norm, k_norm, rope) followed by the store at
+ * nanovllm/layers/attention.py:230-231, in one launch.
+ *   q_w, k_w: [D] bf16 norm weights, or NULL for models without q/k-norm.
+ *   The normalised value is rounded to bf16 before the rotation, as two separate
+ *   modules would do.
+ *   slot_mapping / k_cache / v_cache may all be NULL to skip the scatter; q_out / k_out
+ *   receive the rotated tensors ([T,H,D] contiguous; k_out may be NULL when the scatter
+ *   is requested and the caller does not need k).
+ */
+NV_API int nv_qknorm_rope_store(const void* q, const void* k, const void* v, const void* q_w,
+                         const void* k_w, const float* cos_sin, const int64_t* positions,
+                         const int32_t* slot_mapping, void* k_cache, void* v_cache,
+                         void* q_out, void* k_out, int T, int H_q, int H_kv, int D,
+                         int64_t max_pos, float eps, int64_t num_blocks, int block_size,
+                         int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NANOVLLM_HIP_H */

@@ -1,0 +1,381 @@
+// Paged decode attention (one query token per sequence) for gfx950.
+//
+// HBM-bandwidth-bound: every K/V byte of the context is read exactly once per step, so
+// the kernel is built around keeping many 16-byte-per-lane loads in flight rather than
+// around matrix cores.
+//
+// Work item = one WAVE = (sequence b, kv head h, key chunk s).  The wave streams its
+// chunk in tiles of 16 keys.  Lane l holds 16 bytes (8 dims) of key (l >> 4) of each
+// 4-key load: dims 8*(l & 15) .. +7, so one wave load instruction covers 4 whole
+// 256-byte K (or V) rows of the head.  Scores are v_dot2 partial sums reduced over the 16
+// lanes of a DPP row; each 16-lane row keeps its own online-softmax state (m, l, acc) for
+// the G = H_q / H_kv query heads sharing the kv head, merged once at the end of the chunk.
+// Chunks are combined by a second small kernel (or written directly when there is one).
+//
+// Semantics: flash_attn_varlen_func(..., causal=True, block_table=...) with seqlen_q == 1
+// as called at nanovllm/layers/attention.py:241-252 (the query sees every cached key,
+// including the one stored earlier in the same forward, :230-231).
+#include "nv_common.h"
+
+#include <stdlib.h>
+
+namespace nv {
+
+constexpr float kNegBig = -1.0e30f;  // finite "minus infinity": keeps exp2(m_old - m_new) NaN-free
+constexpr int kPartStride = kHeadDim + 4;  // fp32 per partial: 128 acc + m + l + 2 pad (16-B rows)
+
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
+    float d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.x),
+                                              __builtin_bit_cast(bf16x2, b.x), 0.f, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.y),
+                                        __builtin_bit_cast(bf16x2, b.y), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.z),
+                                        __builtin_bit_cast(bf16x2, b.z), d, false);
+    d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.w),
+                                        __builtin_bit_cast(bf16x2, b.w), d, false);
+    return d;
+}
+
+struct DecodeParams {
+    const uint4* q;
+    const uint4* k_cache;
+    const uint4* v_cache;
+    uint4* o;
+    const int32_t* cu_q;
+    const int32_t* cu_k;
+    const int32_t* block_tables;
+    float* part;  // [B, H_q, nsplit, kPartStride]
+    int B, max_blocks, H_kv, block_size;
+    int chunk, nsplit;
+    int64_t num_blocks;
+    int64_t q_stride_vec, o_stride_vec;
+    float scale_log2;
+};
+
+template <int G, bool ALIGNED>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kq = lane >> 4;  // which of the 4 keys of a load this lane holds
+    const int c = lane & 15;   // which 16-byte piece of the 256-byte head row
+
+    // item -> (b, split, h), h fastest: the waves of a workgroup read neighbouring head
+    // rows of the same tokens, i.e. whole contiguous cache rows.
+    const int item = blockIdx.x * 4 + wave;
+    const int h = item % p.H_kv;
+    const int rest = item / p.H_kv;
+    const int split = rest % p.nsplit;
+    const int b = rest / p.nsplit;
+    if (b >= p.B) return;
+
+    const int n_k = p.cu_k[b + 1] - p.cu_k[b];
+    int tq = b;
+    if (p.cu_q) {
+        if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // not a decode row
+        tq = p.cu_q[b];
+    }
+    const int k0 = split * p.chunk;
+    if (k0 >= n_k && !(split == 0)) return;
+    const int k1 = min(k0 + p.chunk, n_k);
+    const int H_q = p.H_kv * G;
+
+    uint4 qv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+        qv[g] = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * G + g) * 16 + c];
+
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+
+    const int n_keys = k1 - k0;
+    const int nt = n_keys > 0 ? (n_keys + 15) >> 4 : 0;
+    const int32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
+    const int row_vec = p.H_kv * 16;  // uint4 per cache token row
+
+    // Load cursor: cache block index and offset of the next tile's first key.  With
+    // block_size a multiple of 16 a 16-key tile never straddles cache blocks, so the
+    // physical block id is one scalar table read per tile; other block sizes resolve the
+    // block per lane.
+    uint4 kc[4], vc[4], kn[4], vn[4];
+    int cur_blk = k0 / p.block_size;
+    int cur_off = k0 - cur_blk * p.block_size;
+    int cur_key = k0;
+    auto tile_load = [&](uint4 (&kd)[4], uint4 (&vd)[4]) {
+        if (ALIGNED) {
+            int64_t phys = __builtin_amdgcn_readfirstlane(bt[cur_blk]);
+            phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
+            const int64_t base = ((phys * p.block_size + cur_off) * p.H_kv + h) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = 4 * i + kq;
+                const int jj = (cur_key + j) < k1 ? j : 0;  // tail rows re-read row 0; masked below
+                const int64_t vec = base + jj * row_vec + c;
+                kd[i] = load_stream16(p.k_cache + vec);
+                vd[i] = load_stream16(p.v_cache + vec);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = cur_key + 4 * i + kq;
+                key = key < k1 ? key : k1 - 1;
+                const int blk = key / p.block_size;
+                const int off = key - blk * p.block_size;
+                int64_t phys = bt[blk];
+                phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
+                const int64_t vec = ((phys * p.block_size + off) * p.H_kv + h) * 16 + c;
+                kd[i] = load_stream16(p.k_cache + vec);
+                vd[i] = load_stream16(p.v_cache + vec);
+            }
+        }
+        cur_key += 16;
+        cur_off += 16;
+        if (cur_off >= p.block_size) {
+            cur_off -= p.block_size;
+            ++cur_blk;
+        }
+    };
+
+    if (nt > 0) tile_load(kc, vc);
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) tile_load(kn, vn);
+
+        float s[4][G];
+        bool valid[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            valid[i] = (k0 + 16 * t + 4 * i + kq) < k1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float d = row16_sum(dot8(kc[i], qv[g])) * p.scale_log2;
+                s[i][g] = valid[i] ? d : kNegBig;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float mn = fmaxf(fmaxf(fmaxf(s[0][g], s[1][g]), fmaxf(s[2][g], s[3][g])), m[g]);
+            const float alpha = __builtin_amdgcn_exp2f(m[g] - mn);
+            m[g] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s[i][g] = valid[i] ? __builtin_amdgcn_exp2f(s[i][g] - mn) : 0.f;
+                ps += s[i][g];
+            }
+            l[g] = l[g] * alpha + ps;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t vu[4] = {vc[i].x, vc[i].y, vc[i].z, vc[i].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float lo = bf16_lo(vu[w]), hi = bf16_hi(vu[w]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    acc[g][2 * w] += s[i][g] * lo;
+                    acc[g][2 * w + 1] += s[i][g] * hi;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kc[i] = kn[i];
+            vc[i] = vn[i];
+        }
+    }
+
+    // Merge the four 16-lane rows of the wave (lanes l, l^16, l^32, l^48 hold the same dims).
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float ma = fmaxf(m[g], __shfl_xor(m[g], 16));
+        ma = fmaxf(ma, __shfl_xor(ma, 32));
+        const float f = __builtin_amdgcn_exp2f(m[g] - ma);
+        float la = l[g] * f;
+        la += __shfl_xor(la, 16);
+        la += __shfl_xor(la, 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = acc[g][j] * f;
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            acc[g][j] = a;
+        }
+        m[g] = ma;
+        l[g] = la;
+    }
+
+    if (kq != 0) return;
+    if (p.nsplit == 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float inv = l[g] > 0.f ? 1.0f / l[g] : 0.f;
+            uint4 ov;
+            ov.x = pack_bf16(acc[g][0] * inv, acc[g][1] * inv);
+            ov.y = pack_bf16(acc[g][2] * inv, acc[g][3] * inv);
+            ov.z = pack_bf16(acc[g][4] * inv, acc[g][5] * inv);
+            ov.w = pack_bf16(acc[g][6] * inv, acc[g][7] * inv);
+            p.o[(int64_t)tq * p.o_stride_vec + (int64_t)(h * G + g) * 16 + c] = ov;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float* dst = p.part + (((int64_t)b * H_q + (h * G + g)) * p.nsplit + split) * kPartStride;
+            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
+            d4[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            d4[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+            if (c == 0) {
+                dst[kHeadDim] = m[g];
+                dst[kHeadDim + 1] = l[g];
+            }
+        }
+    }
+}
+
+// Combine the per-chunk partial states of one (sequence, query head): 128 threads, one per dim.
+__global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int H_q) {
+    const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
+    const int d = threadIdx.x & 127;
+    if (pair >= p.B * H_q) return;
+    const int b = pair / H_q;
+    const int hq = pair - b * H_q;
+    const int n_k = p.cu_k[b + 1] - p.cu_k[b];
+    int tq = b;
+    if (p.cu_q) {
+        if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;
+        tq = p.cu_q[b];
+    }
+    int ns = (n_k + p.chunk - 1) / p.chunk;
+    ns = ns < 1 ? 1 : ns;  // split 0 always writes a (possibly empty) state
+    const float* base = p.part + ((int64_t)b * H_q + hq) * p.nsplit * kPartStride;
+    float mmax = kNegBig;
+    for (int s = 0; s < ns; ++s) mmax = fmaxf(mmax, base[s * kPartStride + kHeadDim]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < ns; ++s) {
+        const float f = __builtin_amdgcn_exp2f(base[s * kPartStride + kHeadDim] - mmax);
+        num += base[s * kPartStride + d] * f;
+        den += base[s * kPartStride + kHeadDim + 1] * f;
+    }
+    const float r = den > 0.f ? num / den : 0.f;
+    __bf16* o = reinterpret_cast<__bf16*>(p.o) + (int64_t)tq * p.o_stride_vec * 8 + hq * kHeadDim;
+    o[d] = (__bf16)r;
+}
+
+// Keys per work item.  Smaller chunks give more, finer-grained waves (better balance on
+// ragged batches, more loads in flight for small batches) at the price of more partials.
+static int choose_chunk(int B, int H_kv, int max_k) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("NV_DECODE_CHUNK");
+        forced = e ? atoi(e) : 0;
+        if (forced < 0 || forced % 16 != 0) forced = 0;
+    }
+    if (forced > 0) return forced;
+    const long long bh = (long long)B * H_kv;
+    const long long target = 8192;  // ~2 waves per wave slot of the chip
+    int chunk = 1024;
+    while (chunk > 64 && bh * ((max_k + chunk - 1) / chunk) < target) chunk >>= 1;
+    return chunk;
+}
+
+static int num_splits(int max_k, int chunk) {
+    const int n = (max_k + chunk - 1) / chunk;
+    return n < 1 ? 1 : n;
+}
+
+}  // namespace nv
+
+extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k) {
+    using namespace nv;
+    if (B <= 0 || H_q <= 0 || H_kv <= 0 || D != kHeadDim || max_seqlen_k < 0) return 0;
+    const int chunk = choose_chunk(B, H_kv, max_seqlen_k);
+    const int ns = num_splits(max_seqlen_k, chunk);
+    if (ns == 1) return 16;
+    return (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
+}
+
+extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                    const int32_t* block_tables, int B, int max_blocks,
+                                    int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
+                                    int block_size, float scale, int64_t q_stride_t,
+                                    int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+    using namespace nv;
+    NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
+                   num_blocks > 0 && block_size > 0,
+               NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
+               max_blocks, max_seqlen_k);
+    NV_REQUIRE(D == kHeadDim, NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: head_dim %d (128 only)", D);
+    NV_REQUIRE(H_q % H_kv == 0, NV_ERR_INVALID_ARG, "nv_attn_decode_paged: H_q %% H_kv != 0");
+    if (B == 0) return NV_OK;
+    NV_REQUIRE(q && k_cache && v_cache && o && cu_seqlens_k && block_tables, NV_ERR_INVALID_ARG,
+               "nv_attn_decode_paged: null pointer");
+    NV_REQUIRE(q_stride_t % 8 == 0 && o_stride_t % 8 == 0 && q_stride_t >= (int64_t)H_q * D &&
+                   o_stride_t >= (int64_t)H_q * D,
+               NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad token strides");
+    NV_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)o |
+                (uintptr_t)workspace) % 16 == 0,
+               NV_ERR_INVALID_ARG, "nv_attn_decode_paged: pointers must be 16-byte aligned");
+    NV_REQUIRE((int64_t)max_blocks * block_size >= max_seqlen_k, NV_ERR_INVALID_ARG,
+               "nv_attn_decode_paged: block table too narrow for max_seqlen_k");
+    const int G = H_q / H_kv;
+    NV_REQUIRE(G == 1 || G == 2 || G == 4 || G == 8, NV_ERR_UNSUPPORTED,
+               "nv_attn_decode_paged: H_q/H_kv = %d (supported: 1, 2, 4, 8)", G);
+
+    DecodeParams p;
+    p.q = (const uint4*)q;
+    p.k_cache = (const uint4*)k_cache;
+    p.v_cache = (const uint4*)v_cache;
+    p.o = (uint4*)o;
+    p.cu_q = cu_seqlens_q;
+    p.cu_k = cu_seqlens_k;
+    p.block_tables = block_tables;
+    p.part = (float*)workspace;
+    p.B = B;
+    p.max_blocks = max_blocks;
+    p.H_kv = H_kv;
+    p.block_size = block_size;
+    p.chunk = choose_chunk(B, H_kv, max_seqlen_k);
+    p.nsplit = num_splits(max_seqlen_k, p.chunk);
+    p.num_blocks = num_blocks;
+    p.q_stride_vec = q_stride_t / 8;
+    p.o_stride_vec = o_stride_t / 8;
+    p.scale_log2 = scale * 1.4426950408889634f;
+    if (p.nsplit > 1) {
+        const int64_t need = (int64_t)B * H_q * p.nsplit * kPartStride * (int64_t)sizeof(float);
+        NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,
+                   "nv_attn_decode_paged: workspace %lld bytes < required %lld",
+                   (long long)workspace_bytes, (long long)need);
+    }
+    const int64_t items = (int64_t)B * p.nsplit * H_kv;
+    const unsigned grid = (unsigned)((items + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    const bool aligned = block_size % 16 == 0 && p.chunk % 16 == 0;
+#define NV_DEC_LAUNCH(GG)                                                                          \
+    do {                                                                                           \
+        if (aligned) hipLaunchKernelGGL((attn_decode_kernel<GG, true>), dim3(grid), dim3(256), 0, st, p);  \
+        else hipLaunchKernelGGL((attn_decode_kernel<GG, false>), dim3(grid), dim3(256), 0, st, p); \
+    } while (0)
+    switch (G) {
+        case 1: NV_DEC_LAUNCH(1); break;
+        case 2: NV_DEC_LAUNCH(2); break;
+        case 4: NV_DEC_LAUNCH(4); break;
+        default: NV_DEC_LAUNCH(8); break;
+    }
+#undef NV_DEC_LAUNCH
+    int rc = check_launch("nv_attn_decode_paged");
+    if (rc != NV_OK) return rc;
+    if (p.nsplit > 1) {
+        const unsigned mgrid = (unsigned)(((int64_t)B * H_q + 1) / 2);
+        hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(mgrid), dim3(256), 0, st, p, H_q);
+        rc = check_launch("nv_attn_decode_paged(merge)");
+    }
+    return rc;
+}

@@ -1,0 +1,80 @@
+"""Attention layer over the paged KV cache, backed by gfx950 HIP kernels.
+
+Drop-in for the reference's ``Attention`` (nanovllm/layers/attention.py:7-37, 210-254):
+same constructor arguments, the same ``k_cache`` / ``v_cache`` attributes that the model
+runner fills with per-layer views ``[num_blocks, block_size, H_kv, D]``
+(nanovllm/engine/model_runner.py:186-192), and ``forward(q, k, v) -> o`` reading the step's
+``CacheContext``.  Where the reference scatters with ``index_put_`` and then calls
+``flash_attn_varlen_func(causal=True, block_table=...)``, this layer runs
+
+  * ``nv_store_kvcache``        -- the slot_mapping scatter (bit-exact),
+  * ``nv_attn_decode_paged``    -- sequences with one query token (bandwidth-bound kernel),
+  * ``nv_attn_prefill_varlen``  -- sequences with several query tokens (bf16 MFMA kernel),
+
+and a mixed step launches both attention kernels, each skipping the other's sequences.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..utils.cache_context import get_context
+
+
+class Attention(nn.Module):
+    """q: [T, H_q, D], k/v: [T, H_kv, D] (flattened "super sequence"), returns [T, H_q, D]."""
+
+    def __init__(self, num_heads: int, head_dim: int, num_kv_heads: int, attn_scale: float,
+                 max_seq_len: int):
+        super().__init__()
+        assert num_heads % num_kv_heads == 0
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.num_kv_heads = num_kv_heads
+        self.attn_scale = attn_scale
+        self.max_seq_len = max_seq_len
+        self.num_queries_per_kv = num_heads // num_kv_heads
+        # bound by the runner after the cache is allocated
+        self.k_cache: torch.Tensor | None = None
+        self.v_cache: torch.Tensor | None = None
+
+    def store_kvcache(self, k: torch.Tensor, v: torch.Tensor, slot_mapping: torch.Tensor,
+                      block_size: int | None = None) -> None:
+        """Scatter the step's K/V rows into the cache.  ``block_size`` is accepted for signature
+        compatibility; the block size actually used is the cache's own second dimension."""
+        if block_size is not None and block_size != self.k_cache.shape[1]:
+            raise ValueError(
+                f"context block_size {block_size} != cache block size {self.k_cache.shape[1]}")
+        ops.store_kvcache(k, v, self.k_cache, self.v_cache, slot_mapping)
+
+    def attend(self, q: torch.Tensor) -> torch.Tensor:
+        """Attention of q against the cache as described by the current context (no store)."""
+        ctx = get_context()
+        B = ctx.cu_seqlens_q.numel() - 1
+        if ctx.max_seqlen_q <= 1:
+            return ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k,
+                                         ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
+                                         cu_seqlens_q=ctx.cu_seqlens_q)
+        n_dec = ctx.num_decode_seqs
+        mixed = n_dec is None or n_dec > 0
+        if n_dec is not None and n_dec == B:  # max_seqlen_q was an over-estimate
+            return ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k,
+                                         ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
+                                         cu_seqlens_q=ctx.cu_seqlens_q)
+        o = ops.attn_prefill_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q, ctx.cu_seqlens_k,
+                                    ctx.block_tables, ctx.max_seqlen_q, ctx.max_seqlen_k,
+                                    self.attn_scale, skip_single_query=mixed)
+        if mixed:
+            ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k, ctx.block_tables,
+                                  ctx.max_seqlen_k, self.attn_scale, cu_seqlens_q=ctx.cu_seqlens_q, out=o)
+        return o
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        ctx = get_context()
+        if self.k_cache is None or self.v_cache is None or self.k_cache.numel() == 0:
+            raise RuntimeError(
+                "Attention.k_cache / v_cache are not bound: this implementation always attends "
+                "through the paged cache (bind per-layer views before the first forward)")
+        self.store_kvcache(k, v, ctx.slot_mapping, ctx.block_size)
+        return self.attend(q)

@@ -1,0 +1,64 @@
+"""Oracle (test infrastructure): RMSNorm and rotary embedding in plain torch on the CPU.
+
+Follows nanovllm/layers/layernorm.py:79-100 and nanovllm/layers/rope.py:5-56 of the reference.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def rmsnorm_ref(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: torch.Tensor | None = None):
+    """RMSNorm.forward (layernorm.py:79-100) as its compiled form evaluates it: fp32 throughout,
+    one rounding to the input dtype after the weight multiply; with a residual the sum is
+    formed in fp32 (:89), emitted rounded as the new residual (:90) and normalised unrounded."""
+    dt = x.dtype
+    xf = x.float()
+    if residual is not None:
+        xf = xf + residual.float()
+        new_res = xf.to(dt)
+    r = torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)   # :95
+    y = (xf * r * weight.float()).to(dt)                           # :96-98, single rounding
+    return (y, new_res) if residual is not None else y
+
+
+def rmsnorm_ref_eager(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: torch.Tensor | None = None):
+    """The same forward as eager PyTorch evaluates the source text: the normalised value is
+    rounded to the input dtype BEFORE the weight multiply (layernorm.py:98).  Differs from the
+    compiled form by at most one ulp of the output dtype."""
+    dt = x.dtype
+    xf = x.float()
+    if residual is not None:
+        xf = xf + residual.float()
+        new_res = xf.to(dt)
+    r = torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)
+    y = (xf * r).to(dt) * weight
+    return (y, new_res) if residual is not None else y
+
+
+def build_cos_sin_cache(rotary_dim: int, max_seq_len: int, base: float) -> torch.Tensor:
+    """rope.py:31-43: fp32 [max_seq_len, 1, rotary_dim] = cos(pos x inv_freq) | sin(...)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.int64).to(torch.float) / rotary_dim))
+    pos = torch.arange(max_seq_len, dtype=torch.float)
+    freqs = torch.einsum("i,j -> ij", pos, inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).unsqueeze(1)
+
+
+def rope_ref(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, cos_sin_cache: torch.Tensor):
+    """rope.py:46-56 with apply_rotary_emb :5-13 (fp32 math, cast back to the input dtype)."""
+    cs = cos_sin_cache[positions]                       # [T, 1, D]
+    cos, sin = cs.chunk(2, dim=-1)
+
+    def rot(x):
+        x1, x2 = torch.chunk(x.float(), 2, dim=-1)
+        return torch.cat((x1 * cos - x2 * sin, x1 * sin + x2 * cos), dim=-1).to(x.dtype)
+
+    return rot(query), rot(key)
+
+
+def qknorm_rope_ref(positions, q, k, q_w, k_w, cos_sin_cache, eps):
+    """q_norm, k_norm, rope chained as nanovllm/model/qwen3.py:67-71 does (each module rounds
+    its output to bf16)."""
+    if q_w is not None:
+        q = rmsnorm_ref(q, q_w, eps)
+        k = rmsnorm_ref(k, k_w, eps)
+    return rope_ref(positions, q, k, cos_sin_cache)

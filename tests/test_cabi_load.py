@@ -1,0 +1,101 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares; host-side module
+contract (constructors, context errors, refusal of CPU tensors).  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+import nanovllm_amd
+from nanovllm_amd import _lib, ops
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nanovllm_hip.h")).read()
+    return re.findall(r"NV_API\s+[\w\s\*]+?\b(nv_\w+)\s*\(", text)
+
+
+def test_header_declares_expected_entry_points():
+    syms = declared_symbols()
+    assert len(syms) == len(set(syms)) >= 11
+    assert set(syms) == set(_lib.PROTOTYPES), "ctypes prototypes and header disagree"
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    dll = _lib.load()
+    for name in declared_symbols():
+        assert hasattr(dll, name), f"{name} not exported"
+    assert dll.nv_abi_version() == _lib.ABI_VERSION
+    assert dll.nv_strerror(0) == b"ok" and dll.nv_strerror(-3) == b"workspace too small"
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    dll = _lib.lib()
+    # head_dim 64 is unsupported; validation happens before any device access
+    assert dll.nv_attn_decode_workspace_bytes(4, 16, 8, 64, 100) == 0
+    rc = dll.nv_attn_decode_paged(None, None, None, None, None, None, None, 4, 1, 16, 16, 8, 64, 1, 16, 1.0,
+                                  2048, 2048, None, 0, None)
+    assert rc == -2 and b"head_dim" in dll.nv_last_error()
+    rc = dll.nv_store_kvcache(None, None, None, None, None, 3, 8, 128, 4, 256, 1024, 1024, None)
+    assert rc == -1 and b"null" in dll.nv_last_error()
+    rc = dll.nv_rmsnorm(None, None, None, 0, 1024, 1024, 1e-6, None)      # zero rows: a no-op
+    assert rc == 0
+    with pytest.raises(_lib.NanoVllmHipError):
+        _lib.check(-1, "x")
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_context_contract():
+    nanovllm_amd.set_context(None)
+    with pytest.raises(RuntimeError, match="CacheContext not set"):
+        nanovllm_amd.get_context()
+    ctx = nanovllm_amd.CacheContext()
+    assert ctx.block_size == 256 and ctx.layer_idx == -1 and ctx.is_prefill is False
+    assert ctx.slot_mapping is None and ctx.max_seqlen_q == 0 and ctx.block_tables is None
+    nanovllm_amd.set_context(ctx)
+    assert nanovllm_amd.get_context() is ctx
+    nanovllm_amd.set_context(None)
+
+
+def test_module_signatures_and_parameters():
+    attn = nanovllm_amd.Attention(16, 128, 8, 128 ** -0.5, 4096)
+    assert attn.num_queries_per_kv == 2 and attn.k_cache is None and attn.v_cache is None
+    with pytest.raises(AssertionError):
+        nanovllm_amd.Attention(10, 128, 4, 1.0, 16)
+    norm = nanovllm_amd.RMSNorm(1024, eps=1e-6, dtype=torch.bfloat16)
+    assert norm.weight.shape == (1024,) and norm.weight.dtype == torch.bfloat16
+    assert [n for n, _ in norm.named_parameters()] == ["weight"]
+    rope = nanovllm_amd.RotaryPositionEmbedding(128, 128, 64, 1e6)
+    assert rope.cos_sin_cache.shape == (64, 1, 128) and rope.cos_sin_cache.dtype == torch.float32
+    assert "cos_sin_cache" not in rope.state_dict()          # non-persistent buffer
+    with pytest.raises(AssertionError):
+        nanovllm_amd.RotaryPositionEmbedding(128, 64, 64, 1e6)
+    nanovllm_amd.get_rope.cache_clear()
+    assert nanovllm_amd.get_rope(128, 128, 32, 1e6) is nanovllm_amd.get_rope(128, 128, 32, 1e6)
+    with pytest.raises(AssertionError):
+        nanovllm_amd.get_rope(128, 128, 32, 1e6, rope_scaling=("llama3",))
+
+
+def test_rope_table_matches_oracle():
+    from oracle.ref_layers import build_cos_sin_cache
+    rope = nanovllm_amd.RotaryPositionEmbedding(128, 128, 512, 1e6)
+    assert torch.equal(rope.cos_sin_cache, build_cos_sin_cache(128, 512, 1e6))
+
+
+def test_ops_refuse_cpu_tensors():
+    x = torch.zeros(4, 1024, dtype=torch.bfloat16)
+    w = torch.ones(1024, dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match="GPU tensor"):
+        ops.rmsnorm(x, w, 1e-6)
+    attn = nanovllm_amd.Attention(4, 128, 2, 1.0, 64)
+    nanovllm_amd.set_context(nanovllm_amd.CacheContext())
+    with pytest.raises(RuntimeError, match="not bound"):
+        attn(torch.zeros(1, 4, 128), torch.zeros(1, 2, 128), torch.zeros(1, 2, 128))
+    nanovllm_amd.set_context(None)

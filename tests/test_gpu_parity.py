@@ -1,0 +1,401 @@
+"""GPU: the HIP kernels, called through the C ABI (ctypes), against the CPU oracle and the golden
+fixtures.  Bars: bit-exact for the KV scatter and block-table indexing (integer/byte work);
+max-abs <= 2e-2 against the fp32 oracle for attention, RMSNorm and rotary outputs (bf16 I/O).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bf16, bits, make_paged_problem
+from oracle import ref_attention, ref_layers
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-2          # max-abs tolerance against the fp32 oracle (inputs ~N(0,1), outputs O(1))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import nanovllm_amd
+    from nanovllm_amd import _lib, ops
+    _lib.lib()                       # raises if the extension is missing: no fallback
+    return nanovllm_amd, ops
+
+
+def to_dev(p):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in p.items()}
+
+
+# ------------------------------------------------------------------ store_kvcache (bit exact)
+def test_store_matches_reference_fixture(hip, golden):
+    _, ops = hip
+    g = golden("g1_store.npz")
+    k_cache, v_cache = bf16(g["k_cache_in"]).to(DEV), bf16(g["v_cache_in"]).to(DEV)
+    ops.store_kvcache(bf16(g["k"]).to(DEV), bf16(g["v"]).to(DEV), k_cache, v_cache,
+                      torch.from_numpy(g["slot_mapping"]).to(DEV))
+    assert torch.equal(bits(k_cache.cpu()), torch.from_numpy(g["k_cache_out"]))
+    assert torch.equal(bits(v_cache.cpu()), torch.from_numpy(g["v_cache_out"]))
+
+
+@pytest.mark.parametrize("T,H_kv,NB,bs", [(1, 8, 2, 256), (257, 8, 6, 256), (4000, 8, 20, 256), (33, 4, 3, 16), (5, 1, 2, 256)])
+def test_store_random_slots_bit_exact(hip, T, H_kv, NB, bs):
+    _, ops = hip
+    g = torch.Generator().manual_seed(T)
+    D = 128
+    # k and v are slices of one fused projection output: token stride > row length
+    kv = torch.randn(T, 2 * H_kv * D, generator=g).bfloat16()
+    k, v = kv[:, :H_kv * D].view(T, H_kv, D), kv[:, H_kv * D:].view(T, H_kv, D)
+    slots = torch.randperm(NB * bs, generator=g)[:T].to(torch.int32)
+    kc = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
+    vc = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    ref_attention.store_kvcache_ref(k, v, kc_ref, vc_ref, slots, bs)
+    kvd = kv.to(DEV)
+    kd, vd = kvd[:, :H_kv * D].view(T, H_kv, D), kvd[:, H_kv * D:].view(T, H_kv, D)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    ops.store_kvcache(kd, vd, kcd, vcd, slots.to(DEV))
+    assert torch.equal(bits(kcd.cpu()), bits(kc_ref)) and torch.equal(bits(vcd.cpu()), bits(vc_ref))
+
+
+def test_store_skips_negative_and_out_of_range_slots(hip):
+    _, ops = hip
+    T, H_kv, D, NB, bs = 4, 8, 128, 2, 256
+    k = torch.ones(T, H_kv, D, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(NB, bs, H_kv, D, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    ops.store_kvcache(k, k, kc, vc, torch.tensor([-1, 5, NB * bs, 7], dtype=torch.int32, device=DEV))
+    touched = kc.view(NB * bs, -1).abs().sum(dim=1).nonzero().flatten().tolist()
+    assert touched == [5, 7]
+
+
+def test_store_empty_batch(hip):
+    _, ops = hip
+    kc = torch.zeros(1, 256, 8, 128, dtype=torch.bfloat16, device=DEV)
+    e = torch.zeros(0, 8, 128, dtype=torch.bfloat16, device=DEV)
+    ops.store_kvcache(e, e, kc, kc.clone(), torch.zeros(0, dtype=torch.int32, device=DEV))
+
+
+# ------------------------------------------------------------------ RMSNorm
+def _check_norm(got, want_bits_or_tensor, name, max_mismatch=2e-3):
+    want = want_bits_or_tensor
+    mism = (bits(got) != bits(want)).float().mean().item()
+    err = (got.float() - want.float()).abs().max().item()
+    assert err <= TOL * max(1.0, want.float().abs().max().item()), (name, err)
+    assert mism <= max_mismatch, (name, "fraction of elements differing from the reference by an ulp", mism)
+
+
+def test_rmsnorm_matches_compiled_reference_fixture(hip, golden):
+    _, ops = hip
+    g = golden("g2_rmsnorm.npz")
+    eps = float(g["eps"])
+    for tag in ("hidden", "head", "wide"):
+        x, res, w = bf16(g[f"{tag}_x"]).to(DEV), bf16(g[f"{tag}_res"]).to(DEV), bf16(g[f"{tag}_w"]).to(DEV)
+        y = ops.rmsnorm(x, w, eps)
+        y2, nr = ops.add_rmsnorm(x, res, w, eps)
+        assert torch.equal(bits(nr.cpu()), torch.from_numpy(g[f"{tag}_new_res"])), tag     # exact sum
+        _check_norm(y.cpu(), bf16(g[f"{tag}_y"]), tag + "_y")
+        _check_norm(y2.cpu(), bf16(g[f"{tag}_y_res"]), tag + "_y_res")
+        assert y.shape == x.shape and y2.shape == x.shape
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 128), (3, 1024), (256, 1024), (7, 2048), (5, 4096), (2, 5120), (1, 16384), (300, 128)])
+def test_rmsnorm_shapes_against_oracle(hip, rows, cols):
+    _, ops = hip
+    g = torch.Generator().manual_seed(rows * 131 + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2).bfloat16()
+    res = torch.randn(rows, cols, generator=g).bfloat16()
+    w = (1 + 0.2 * torch.randn(cols, generator=g)).bfloat16()
+    y = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6).cpu()
+    y2, nr = ops.add_rmsnorm(x.to(DEV), res.to(DEV), w.to(DEV), 1e-6)
+    ro = ref_layers.rmsnorm_ref(x, w, 1e-6)
+    ro2, rnr = ref_layers.rmsnorm_ref(x, w, 1e-6, res)
+    assert torch.equal(bits(nr.cpu()), bits(rnr))
+    _check_norm(y, ro, "y")
+    _check_norm(y2.cpu(), ro2, "y_res")
+
+
+def test_rmsnorm_module_and_input_preserved(hip):
+    nv, _ = hip
+    norm = nv.RMSNorm(1024, eps=1e-6, dtype=torch.bfloat16, device=DEV)
+    x = torch.randn(16, 1024, device=DEV).bfloat16()
+    res = torch.randn(16, 1024, device=DEV).bfloat16()
+    x0, r0 = x.clone(), res.clone()
+    y = norm(x)
+    y2, nr = norm(x, res)
+    assert torch.equal(x, x0) and torch.equal(res, r0)            # inputs untouched
+    assert y.dtype == torch.bfloat16 and nr.shape == x.shape
+    want, want_nr = ref_layers.rmsnorm_ref(x.cpu(), norm.weight.data.cpu(), 1e-6, res.cpu())
+    _check_norm(y2.cpu(), want, "module")
+    assert torch.equal(bits(nr.cpu()), bits(want_nr))
+
+
+# ------------------------------------------------------------------ rotary embedding
+def test_rope_matches_reference_fixture(hip, golden):
+    nv, _ = hip
+    g = golden("g3_rope.npz")
+    rope = nv.RotaryPositionEmbedding(int(g["head_dim"]), int(g["head_dim"]), int(g["max_pos"]), float(g["base"])).to(DEV)
+    qo, ko = rope(torch.from_numpy(g["positions"]).to(DEV), bf16(g["q"]).to(DEV), bf16(g["k"]).to(DEV))
+    # separately rounded products and one final rounding: the same fp32 expression tree as the reference
+    assert torch.equal(bits(qo.cpu()), torch.from_numpy(g["q_out"]))
+    assert torch.equal(bits(ko.cpu()), torch.from_numpy(g["k_out"]))
+
+
+@pytest.mark.parametrize("T,H_q,H_kv", [(1, 16, 8), (256, 16, 8), (37, 64, 8), (5, 32, 8), (3, 4, 4)])
+def test_rope_strided_inputs_against_oracle(hip, T, H_q, H_kv):
+    _, ops = hip
+    D, max_pos = 128, 4096
+    g = torch.Generator().manual_seed(T + H_q)
+    qkv = torch.randn(T, (H_q + 2 * H_kv) * D, generator=g).bfloat16()
+    q = qkv[:, :H_q * D].view(T, H_q, D)
+    k = qkv[:, H_q * D:(H_q + H_kv) * D].view(T, H_kv, D)
+    pos = torch.randint(0, max_pos, (T,), generator=g, dtype=torch.int64)
+    table = ref_layers.build_cos_sin_cache(D, max_pos, 1e6)
+    rq, rk = ref_layers.rope_ref(pos, q, k, table)
+    qd = qkv.to(DEV)
+    qo, ko = ops.rope(pos.to(DEV), qd[:, :H_q * D].view(T, H_q, D), qd[:, H_q * D:(H_q + H_kv) * D].view(T, H_kv, D),
+                      table.to(DEV))
+    assert torch.equal(bits(qo.cpu()), bits(rq)) and torch.equal(bits(ko.cpu()), bits(rk))
+
+
+@pytest.mark.parametrize("norm", [True, False])
+@pytest.mark.parametrize("T,H_q,H_kv", [(1, 16, 8), (256, 16, 8), (19, 64, 8), (512, 32, 8)])
+def test_fused_qknorm_rope_store_against_oracle(hip, T, H_q, H_kv, norm):
+    _, ops = hip
+    D, max_pos, NB, bs = 128, 2048, 4, 256
+    g = torch.Generator().manual_seed(T * 7 + H_q)
+    q = torch.randn(T, H_q, D, generator=g).bfloat16()
+    k = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    v = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    qw = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16() if norm else None
+    kw = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16() if norm else None
+    pos = torch.randint(0, max_pos, (T,), generator=g, dtype=torch.int64)
+    slots = torch.randperm(NB * bs, generator=g)[:T].to(torch.int32)
+    table = ref_layers.build_cos_sin_cache(D, max_pos, 1e6)
+    kc = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
+    vc = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
+    rq, rk = ref_layers.qknorm_rope_ref(pos, q, k, qw, kw, table, 1e-6)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    ref_attention.store_kvcache_ref(rk, v, kc_ref, vc_ref, slots, bs)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    qo, ko = ops.qknorm_rope_store(pos.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV),
+                                   qw.to(DEV) if norm else None, kw.to(DEV) if norm else None,
+                                   table.to(DEV), 1e-6, slots.to(DEV), kcd, vcd)
+    if norm:
+        _check_norm(qo.cpu(), rq, "q", max_mismatch=5e-3)
+        _check_norm(ko.cpu(), rk, "k", max_mismatch=5e-3)
+    else:
+        assert torch.equal(bits(qo.cpu()), bits(rq)) and torch.equal(bits(ko.cpu()), bits(rk))
+    # the scatter itself is exact: the cache holds exactly what the kernel returned as k, and v
+    kc_exp, vc_exp = kc.clone(), vc.clone()
+    ref_attention.store_kvcache_ref(ko.cpu(), v, kc_exp, vc_exp, slots, bs)
+    assert torch.equal(bits(kcd.cpu()), bits(kc_exp)) and torch.equal(bits(vcd.cpu()), bits(vc_ref))
+
+
+# ------------------------------------------------------------------ attention
+def _attn_check(o, ref, name):
+    err = (o.float().cpu() - ref).abs().max().item()
+    assert err <= TOL, (name, err)
+    return err
+
+
+def _run_attention(ops, p, mode):
+    if mode == "decode":
+        return ops.attn_decode_paged(p["q"], p["k_cache"], p["v_cache"], p["cu_k"], p["block_tables"], p["max_k"],
+                                     p["scale"], cu_seqlens_q=p["cu_q"])
+    if mode == "prefill":
+        return ops.attn_prefill_varlen(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"], p["block_tables"],
+                                       p["max_q"], p["max_k"], p["scale"])
+    o = ops.attn_prefill_varlen(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"], p["block_tables"],
+                                p["max_q"], p["max_k"], p["scale"], skip_single_query=True)
+    return ops.attn_decode_paged(p["q"], p["k_cache"], p["v_cache"], p["cu_k"], p["block_tables"], p["max_k"],
+                                 p["scale"], cu_seqlens_q=p["cu_q"], out=o)
+
+
+def test_attention_golden_cases(hip, golden):
+    _, ops = hip
+    g = golden("g4_attention.npz")
+    for name in g["names"]:
+        cu_q, cu_k = g[f"{name}_cu_q"], g[f"{name}_cu_k"]
+        n_q = np.diff(cu_q)
+        p = dict(q=bf16(g[f"{name}_q"]), k_cache=bf16(g[f"{name}_k_cache"]), v_cache=bf16(g[f"{name}_v_cache"]),
+                 cu_q=torch.from_numpy(cu_q), cu_k=torch.from_numpy(cu_k),
+                 block_tables=torch.from_numpy(g[f"{name}_block_tables"]), scale=float(g[f"{name}_scale"]),
+                 max_q=int(n_q.max()), max_k=int(np.diff(cu_k).max()))
+        p = to_dev(p)
+        ref = torch.from_numpy(g[f"{name}_out"])
+        modes = ["mixed", "prefill"] + (["decode"] if n_q.max() == 1 else [])
+        for mode in modes:
+            _attn_check(_run_attention(ops, p, mode), ref, f"{name}/{mode}")
+
+
+@pytest.mark.parametrize("H_q,H_kv", [(16, 8), (32, 8), (64, 8), (8, 8), (8, 1)])
+@pytest.mark.parametrize("bs", [256, 16])
+def test_decode_ragged_against_oracle(hip, H_q, H_kv, bs):
+    _, ops = hip
+    n_ks = [1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 513, 700, 768]
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 2
+    p = make_paged_problem(H_q * 3 + bs, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    o = ops.attn_decode_paged(pd["q"], pd["k_cache"], pd["v_cache"], pd["cu_k"], pd["block_tables"], p["max_k"],
+                              p["scale"])                                   # cu_seqlens_q omitted: token b = seq b
+    _attn_check(o, ref, "decode")
+    o2 = _run_attention(ops, pd, "decode")
+    assert torch.equal(o, o2)
+
+
+def test_decode_long_context_split(hip):
+    """Few sequences, long contexts: many key chunks per (sequence, head) and the merge kernel."""
+    _, ops = hip
+    n_ks = [4097, 3000, 8192]
+    p = make_paged_problem(5, [1, 1, 1], n_ks, 32, 8, 256, 64)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    _attn_check(_run_attention(ops, pd, "decode"), ref, "decode-long")
+
+
+def test_decode_zero_length_sequence_gives_zeros(hip):
+    _, ops = hip
+    p = make_paged_problem(9, [1, 1], [0, 40], 16, 8, 256, 3)
+    p["block_tables"][0, :] = -1
+    pd = to_dev(p)
+    o = _run_attention(ops, pd, "decode").cpu().float()
+    assert o[0].abs().max().item() == 0.0
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(o, ref, "decode-empty")
+
+
+def test_decode_ignores_uninitialised_cache_rows(hip):
+    """Rows of the cache beyond a sequence's length may hold NaN bit patterns (torch.empty)."""
+    _, ops = hip
+    p = make_paged_problem(11, [1, 1, 1], [5, 70, 257], 16, 8, 256, 5)
+    nan = torch.tensor(float("nan")).bfloat16()
+    for b, n in enumerate([5, 70, 257]):
+        for j in range(n, ((n + 255) // 256) * 256):
+            blk = p["block_tables"][b, j // 256].item()
+            p["k_cache"][blk, j % 256] = nan
+            p["v_cache"][blk, j % 256] = nan
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    _attn_check(_run_attention(ops, pd, "decode"), ref, "decode-nan-tail")
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "prefill-nan-tail")
+
+
+@pytest.mark.parametrize("H_q,H_kv", [(16, 8), (32, 8), (4, 4)])
+@pytest.mark.parametrize("n_qs,n_ks", [
+    ([512], [512]),                         # full prefill, one sequence
+    ([1, 31, 32, 33, 127, 128, 129], [1, 31, 32, 33, 127, 128, 129]),   # ragged full prefill
+    ([512, 512, 300], [1024, 512, 812]),    # chunked prefill: keys already cached
+    ([5], [13]),
+    ([64, 1, 200, 1], [64, 300, 456, 1]),   # mixed with decode rows
+])
+def test_prefill_against_oracle(hip, H_q, H_kv, n_qs, n_ks):
+    _, ops = hip
+    bs = 256
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+    p = make_paged_problem(sum(n_ks) + H_q, n_qs, n_ks, H_q, H_kv, bs, nb)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "prefill")
+    _attn_check(_run_attention(ops, pd, "mixed"), ref, "mixed")
+
+
+def test_prefill_block_size_64_and_strided_q(hip):
+    _, ops = hip
+    p = make_paged_problem(77, [100, 260], [164, 260], 8, 2, 64, 9)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    T, H_q, D = p["q"].shape
+    wide = torch.zeros(T, H_q * D + 512, dtype=torch.bfloat16, device=DEV)
+    wide[:, :H_q * D] = pd["q"].view(T, -1)
+    pd["q"] = wide[:, :H_q * D].view(T, H_q, D)                 # token stride larger than the row
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "prefill-bs64")
+
+
+def test_prefill_online_softmax_rescale_is_exercised(hip):
+    """A late key with a much larger score forces the running max to jump in the last tile."""
+    _, ops = hip
+    p = make_paged_problem(3, [256], [256], 4, 2, 256, 2)
+    blk = p["block_tables"][0, 0].item()
+    p["k_cache"][blk, 250] = (p["q"][255, 0] * 3).to(torch.bfloat16)[None, :].expand(2, -1)   # spike for query 255
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-spike")
+    p2 = make_paged_problem(4, [1], [600], 4, 2, 256, 4)
+    blk = p2["block_tables"][0, 2].item()
+    p2["k_cache"][blk, 80] = (p2["q"][0, 1] * 3).to(torch.bfloat16)[None, :].expand(2, -1)
+    ref2 = ref_attention.paged_attention_ref(p2["q"], p2["k_cache"], p2["v_cache"], p2["cu_q"], p2["cu_k"],
+                                             p2["block_tables"], p2["scale"])
+    _attn_check(_run_attention(ops, to_dev(p2), "decode"), ref2, "decode-spike")
+
+
+def test_attention_module_forward_stores_then_attends(hip):
+    """Attention.forward: scatter the step's K/V, then attend through the cache (mixed batch)."""
+    nv, _ = hip
+    H_q, H_kv, D, bs, NB = 16, 8, 128, 256, 6
+    n_qs, n_ks = [1, 130, 1], [300, 130, 17]
+    p = make_paged_problem(21, n_qs, n_ks, H_q, H_kv, bs, NB)
+    T = sum(n_qs)
+    g = torch.Generator().manual_seed(5)
+    k_new = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    v_new = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    slots = []
+    for b, (nq, nk) in enumerate(zip(n_qs, n_ks)):
+        for pos in range(nk - nq, nk):
+            slots.append(p["block_tables"][b, pos // bs].item() * bs + pos % bs)
+    slots = torch.tensor(slots, dtype=torch.int32)
+    kc_ref, vc_ref = p["k_cache"].clone(), p["v_cache"].clone()
+    ref = ref_attention.attention_forward_ref(p["q"], k_new, v_new, kc_ref, vc_ref, slots, p["cu_q"], p["cu_k"],
+                                              p["block_tables"], p["scale"], bs)
+    attn = nv.Attention(H_q, D, H_kv, p["scale"], 4096)
+    attn.k_cache, attn.v_cache = p["k_cache"].to(DEV), p["v_cache"].to(DEV)
+    for n_dec in (None, 2):
+        nv.set_context(nv.CacheContext(slot_mapping=slots.to(DEV), cu_seqlens_q=p["cu_q"].to(DEV),
+                                       cu_seqlens_k=p["cu_k"].to(DEV), max_seqlen_q=max(n_qs), max_seqlen_k=max(n_ks),
+                                       block_tables=p["block_tables"].to(DEV), block_size=bs, num_decode_seqs=n_dec))
+        o = attn(p["q"].to(DEV), k_new.to(DEV), v_new.to(DEV))
+        _attn_check(o, ref, "module")
+    assert torch.equal(bits(attn.k_cache.cpu()), bits(kc_ref)) and torch.equal(bits(attn.v_cache.cpu()), bits(vc_ref))
+    nv.set_context(None)
+
+
+def test_full_size_decode_properties(hip):
+    """BASELINE size (Qwen3-0.6B shapes, B=256, ctx 513..768, block 256): checked through
+    size-independent properties instead of the slow oracle: (1) V == const -> output == const;
+    (2) softmax-weighted outputs are convex combinations: |o| <= max|v|; (3) a sample of
+    sequences against the oracle; (4) permuting the physical blocks (and the tables with them)
+    leaves the output bit-identical."""
+    _, ops = hip
+    B, H_q, H_kv, D, bs = 256, 16, 8, 128, 256
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randint(513, 769, (B,), generator=g).tolist()
+    NB = sum((c + bs - 1) // bs for c in ctx)
+    p = make_paged_problem(0, [1] * B, ctx, H_q, H_kv, bs, NB, pad_cols=0)
+    pd = to_dev(p)
+    o = _run_attention(ops, pd, "decode")
+    assert o.float().abs().max().item() <= p["v_cache"].float().abs().max().item() + 1e-3
+    sample = [0, 17, 101, 255]
+    for b in sample:
+        sub = dict(q=p["q"][b:b + 1], cu_q=torch.tensor([0, 1], dtype=torch.int32),
+                   cu_k=torch.tensor([0, ctx[b]], dtype=torch.int32), block_tables=p["block_tables"][b:b + 1])
+        ref = ref_attention.paged_attention_ref(sub["q"], p["k_cache"], p["v_cache"], sub["cu_q"], sub["cu_k"],
+                                                sub["block_tables"], p["scale"])
+        _attn_check(o[b:b + 1], ref, f"full-size seq {b}")
+    const = pd["v_cache"].clone().fill_(0.75)
+    oc = ops.attn_decode_paged(pd["q"], pd["k_cache"], const, pd["cu_k"], pd["block_tables"], p["max_k"], p["scale"])
+    assert (oc.float() - 0.75).abs().max().item() <= 4e-3
+    perm = torch.randperm(NB, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(NB)
+    k2, v2 = p["k_cache"][perm].to(DEV), p["v_cache"][perm].to(DEV)      # new block i holds old block perm[i]
+    bt2 = inv[p["block_tables"].long()].to(torch.int32).to(DEV)
+    o2 = ops.attn_decode_paged(pd["q"], k2, v2, pd["cu_k"], bt2, p["max_k"], p["scale"])
+    assert torch.equal(o, o2)

@@ -1,0 +1,128 @@
+"""CPU: the oracle restatement against the golden fixtures captured from the reference."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN, bf16, bits
+from oracle import ref_attention, ref_layers, ref_metadata
+
+
+def test_store_kvcache_matches_reference_fixture(golden):
+    g = golden("g1_store.npz")
+    k_cache, v_cache = bf16(g["k_cache_in"]).clone(), bf16(g["v_cache_in"]).clone()
+    ref_attention.store_kvcache_ref(bf16(g["k"]), bf16(g["v"]), k_cache, v_cache,
+                                    torch.from_numpy(g["slot_mapping"]), int(g["block_size"]))
+    assert torch.equal(bits(k_cache), torch.from_numpy(g["k_cache_out"]))
+    assert torch.equal(bits(v_cache), torch.from_numpy(g["v_cache_out"]))
+
+
+def test_rmsnorm_matches_compiled_reference(golden):
+    g = golden("g2_rmsnorm.npz")
+    eps = float(g["eps"])
+    for tag in ("hidden", "head", "wide"):
+        x, res, w = bf16(g[f"{tag}_x"]), bf16(g[f"{tag}_res"]), bf16(g[f"{tag}_w"])
+        y = ref_layers.rmsnorm_ref(x, w, eps)
+        y2, nr = ref_layers.rmsnorm_ref(x, w, eps, res)
+        assert torch.equal(bits(nr), torch.from_numpy(g[f"{tag}_new_res"]))          # bit exact
+        for got, key in ((y, f"{tag}_y"), (y2, f"{tag}_y_res")):
+            want = bf16(g[key])
+            mism = (bits(got) != bits(want)).float().mean().item()
+            assert mism <= 1e-3, (tag, key, mism)           # reduction order: rare 1-ulp flips
+            assert (got.float() - want.float()).abs().max().item() <= 2e-2 * max(1.0, want.float().abs().max().item())
+
+
+def test_rmsnorm_eager_form_is_within_one_ulp(golden):
+    g = golden("g2_rmsnorm.npz")
+    x, w = bf16(g["hidden_x"]), bf16(g["hidden_w"])
+    a = ref_layers.rmsnorm_ref(x, w, 1e-6).float()
+    b = ref_layers.rmsnorm_ref_eager(x, w, 1e-6).float()
+    assert ((a - b).abs() <= a.abs() * 2 ** -7 + 1e-6).all()
+
+
+def test_rope_matches_reference_fixture(golden):
+    g = golden("g3_rope.npz")
+    D, max_pos, base = int(g["head_dim"]), int(g["max_pos"]), float(g["base"])
+    table = ref_layers.build_cos_sin_cache(D, max_pos, base)
+    pos = torch.from_numpy(g["positions"])
+    assert torch.equal(table[pos, 0], torch.from_numpy(g["cos_sin_rows"]))
+    qo, ko = ref_layers.rope_ref(pos, bf16(g["q"]), bf16(g["k"]), table)
+    assert torch.equal(bits(qo), torch.from_numpy(g["q_out"]))
+    assert torch.equal(bits(ko), torch.from_numpy(g["k_out"]))
+
+
+def test_attention_fixture_is_reproducible(golden):
+    g = golden("g4_attention.npz")
+    for name in g["names"]:
+        o = ref_attention.paged_attention_ref(bf16(g[f"{name}_q"]), bf16(g[f"{name}_k_cache"]),
+                                              bf16(g[f"{name}_v_cache"]), torch.from_numpy(g[f"{name}_cu_q"]),
+                                              torch.from_numpy(g[f"{name}_cu_k"]),
+                                              torch.from_numpy(g[f"{name}_block_tables"]), float(g[f"{name}_scale"]))
+        assert torch.allclose(o, torch.from_numpy(g[f"{name}_out"]), atol=1e-5, rtol=1e-5), name
+
+
+def test_attention_bottom_right_mask_small_case():
+    """n_q=2, n_k=3: query 0 sees keys 0..1, query 1 sees keys 0..2; and decode == no mask."""
+    D = 128
+    q = torch.zeros(2, 1, D).bfloat16()
+    k_cache = torch.zeros(1, 4, 1, D).bfloat16()
+    v_cache = torch.zeros(1, 4, 1, D).bfloat16()
+    v_cache[0, 0, 0, 0], v_cache[0, 1, 0, 0], v_cache[0, 2, 0, 0] = 1.0, 2.0, 6.0
+    o = ref_attention.paged_attention_ref(q, k_cache, v_cache, torch.tensor([0, 2], dtype=torch.int32),
+                                          torch.tensor([0, 3], dtype=torch.int32),
+                                          torch.tensor([[0]], dtype=torch.int32), 1.0)
+    assert abs(o[0, 0, 0].item() - 1.5) < 1e-6       # mean of keys 0,1
+    assert abs(o[1, 0, 0].item() - 3.0) < 1e-6       # mean of keys 0,1,2
+
+
+def test_attention_rows_without_keys_are_zero():
+    D = 128
+    q = torch.ones(3, 1, D).bfloat16()
+    k_cache = torch.ones(1, 4, 1, D).bfloat16()
+    v_cache = torch.ones(1, 4, 1, D).bfloat16()
+    # n_q=3 > n_k=1: queries 0 and 1 see nothing (bottom-right alignment), query 2 sees key 0
+    o = ref_attention.paged_attention_ref(q, k_cache, v_cache, torch.tensor([0, 3], dtype=torch.int32),
+                                          torch.tensor([0, 1], dtype=torch.int32),
+                                          torch.tensor([[0]], dtype=torch.int32), 1.0)
+    assert o[0].abs().max() == 0 and o[1].abs().max() == 0 and abs(o[2, 0, 0].item() - 1.0) < 1e-6
+
+
+def test_block_hash_known_answers():
+    import xxhash
+    with open(os.path.join(GOLDEN, "g5_hash.json")) as f:
+        vectors = json.load(f)
+    assert vectors[0]["hash"] == 2877822695146591398 and vectors[1]["hash"] == 17010504966165004578
+    for v in vectors:
+        h = xxhash.xxh64()
+        if v["prev"] != -1:
+            h.update(int(v["prev"]).to_bytes(8, "little"))
+        h.update(np.array(v["tokens"], dtype=np.int32).tobytes())
+        assert h.intdigest() == v["hash"]
+
+
+class _Seq:
+    def __init__(self, prompt, outputs, computed, scheduled, table):
+        self.prompt_tokens, self.output_tokens = prompt, outputs
+        self.num_computed_tokens, self.num_scheduled_tokens, self.block_table = computed, scheduled, table
+
+    @property
+    def is_prefill(self):
+        return len(self.output_tokens) == 0
+
+    @property
+    def num_tokens(self):
+        return len(self.prompt_tokens) + len(self.output_tokens)
+
+
+def test_metadata_builder_integers():
+    """Hand-computed expectations for nanovllm/engine/model_runner.py:56-119 (block_size 4)."""
+    a = _Seq(list(range(100, 110)), [], 4, 6, [7, 2, 5])          # chunked prefill, positions 4..9
+    b = _Seq([1, 2, 3], [50, 51], 4, 1, [9, 0])                    # decode: last output at position 4
+    m = ref_metadata.prepare_inputs_ref([a, b], 4)
+    assert m["input_ids"] == [104, 105, 106, 107, 108, 109, 51]
+    assert m["positions"] == [4, 5, 6, 7, 8, 9, 4]
+    assert m["slot_mapping"] == [2 * 4 + 0, 2 * 4 + 1, 2 * 4 + 2, 2 * 4 + 3, 5 * 4 + 0, 5 * 4 + 1, 0 * 4 + 0]
+    assert m["cu_seqlens_q"] == [0, 6, 7] and m["cu_seqlens_k"] == [0, 10, 15]
+    assert m["max_seqlen_q"] == 6 and m["max_seqlen_k"] == 10
+    assert m["block_tables"] == [[7, 2, 5], [9, 0, -1]]
