@@ -164,17 +164,19 @@ __device__ __forceinline__ void head_norm_rope(const uint4* __restrict__ src,  /
     const float co[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float si[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     uint32_t o1[4], o2[4];
+    {
+        // The reference evaluates x1*cos - x2*sin as separate fp32 tensor ops: every product
+        // is rounded before the add.  Keep the compiler from fusing them into FMAs.
+#pragma clang fp contract(off)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        // products rounded separately, as the reference's fp32 tensor expression does
-        const float y1a = __fsub_rn(__fmul_rn(x1[2 * j], co[2 * j]), __fmul_rn(x2[2 * j], si[2 * j]));
-        const float y1b = __fsub_rn(__fmul_rn(x1[2 * j + 1], co[2 * j + 1]),
-                                    __fmul_rn(x2[2 * j + 1], si[2 * j + 1]));
-        const float y2a = __fadd_rn(__fmul_rn(x1[2 * j], si[2 * j]), __fmul_rn(x2[2 * j], co[2 * j]));
-        const float y2b = __fadd_rn(__fmul_rn(x1[2 * j + 1], si[2 * j + 1]),
-                                    __fmul_rn(x2[2 * j + 1], co[2 * j + 1]));
-        o1[j] = pack_bf16(y1a, y1b);
-        o2[j] = pack_bf16(y2a, y2b);
+        for (int j = 0; j < 4; ++j) {
+            const float a1 = x1[2 * j] * co[2 * j], a2 = x2[2 * j] * si[2 * j];
+            const float b1 = x1[2 * j + 1] * co[2 * j + 1], b2 = x2[2 * j + 1] * si[2 * j + 1];
+            const float c1 = x1[2 * j] * si[2 * j], c2 = x2[2 * j] * co[2 * j];
+            const float d1 = x1[2 * j + 1] * si[2 * j + 1], d2 = x2[2 * j + 1] * co[2 * j + 1];
+            o1[j] = pack_bf16(a1 - a2, b1 - b2);
+            o2[j] = pack_bf16(c1 + c2, d1 + d2);
+        }
     }
     out1 = make_uint4(o1[0], o1[1], o1[2], o1[3]);
     out2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);

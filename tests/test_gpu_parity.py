@@ -138,8 +138,8 @@ def test_rope_matches_reference_fixture(hip, golden):
     rope = nv.RotaryPositionEmbedding(int(g["head_dim"]), int(g["head_dim"]), int(g["max_pos"]), float(g["base"])).to(DEV)
     qo, ko = rope(torch.from_numpy(g["positions"]).to(DEV), bf16(g["q"]).to(DEV), bf16(g["k"]).to(DEV))
     # separately rounded products and one final rounding: the same fp32 expression tree as the reference
-    assert torch.equal(bits(qo.cpu()), torch.from_numpy(g["q_out"]))
-    assert torch.equal(bits(ko.cpu()), torch.from_numpy(g["k_out"]))
+    assert (bits(qo.cpu()) != torch.from_numpy(g["q_out"])).sum().item() == 0
+    assert (bits(ko.cpu()) != torch.from_numpy(g["k_out"])).sum().item() == 0
 
 
 @pytest.mark.parametrize("T,H_q,H_kv", [(1, 16, 8), (256, 16, 8), (37, 64, 8), (5, 32, 8), (3, 4, 4)])
