@@ -19,8 +19,21 @@
 
 #include <stdlib.h>
 
+// Build-time tuning knobs (defaults are the measured best on MI355X).
+#ifndef NV_DEC_WAVES
+#define NV_DEC_WAVES 4   // waves (work items) per workgroup
+#endif
+#ifndef NV_DEC_NT
+#define NV_DEC_NT 1      // 1: K/V loads carry the non-temporal hint (read-once stream)
+#endif
+
+#ifndef NV_DEC_TARGET_WAVES
+#define NV_DEC_TARGET_WAVES 2048   // split the keys until the launch has about this many waves
+#endif
+
 namespace nv {
 
+constexpr int kDecWaves = NV_DEC_WAVES;
 constexpr float kNegBig = -1.0e30f;  // finite "minus infinity": keeps exp2(m_old - m_new) NaN-free
 constexpr int kPartStride = kHeadDim + 4;  // fp32 per partial: 128 acc + m + l + 2 pad (16-B rows)
 
@@ -34,6 +47,14 @@ __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
     d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a.w),
                                         __builtin_bit_cast(bf16x2, b.w), d, false);
     return d;
+}
+
+__device__ __forceinline__ uint4 kv_load(const uint4* p) {
+#if NV_DEC_NT
+    return load_stream16(p);
+#else
+    return *p;
+#endif
 }
 
 struct DecodeParams {
@@ -52,8 +73,9 @@ struct DecodeParams {
     float scale_log2;
 };
 
-template <int G, bool ALIGNED>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) {
+// kDepth = tiles (8 KiB per wave each) kept in flight ahead of the one being consumed.
+template <int G, bool ALIGNED, int kDepth>
+__global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const DecodeParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kq = lane >> 4;  // which of the 4 keys of a load this lane holds
@@ -61,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
 
     // item -> (b, split, h), h fastest: the waves of a workgroup read neighbouring head
     // rows of the same tokens, i.e. whole contiguous cache rows.
-    const int item = blockIdx.x * 4 + wave;
+    const int item = blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
     const int split = rest % p.nsplit;
@@ -102,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     // block_size a multiple of 16 a 16-key tile never straddles cache blocks, so the
     // physical block id is one scalar table read per tile; other block sizes resolve the
     // block per lane.
-    uint4 kc[4], vc[4], kn[4], vn[4];
+    uint4 kbuf[kDepth + 1][4], vbuf[kDepth + 1][4];
     int cur_blk = k0 / p.block_size;
     int cur_off = k0 - cur_blk * p.block_size;
     int cur_key = k0;
@@ -116,8 +138,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
                 const int j = 4 * i + kq;
                 const int jj = (cur_key + j) < k1 ? j : 0;  // tail rows re-read row 0; masked below
                 const int64_t vec = base + jj * row_vec + c;
-                kd[i] = load_stream16(p.k_cache + vec);
-                vd[i] = load_stream16(p.v_cache + vec);
+                kd[i] = kv_load(p.k_cache + vec);
+                vd[i] = kv_load(p.v_cache + vec);
             }
         } else {
 #pragma unroll
@@ -129,8 +151,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
                 int64_t phys = bt[blk];
                 phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
                 const int64_t vec = ((phys * p.block_size + off) * p.H_kv + h) * 16 + c;
-                kd[i] = load_stream16(p.k_cache + vec);
-                vd[i] = load_stream16(p.v_cache + vec);
+                kd[i] = kv_load(p.k_cache + vec);
+                vd[i] = kv_load(p.v_cache + vec);
             }
         }
         cur_key += 16;
@@ -141,10 +163,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
         }
     };
 
-    if (nt > 0) tile_load(kc, vc);
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) tile_load(kn, vn);
-
+    // One tile: scores for 16 keys (4 per 16-lane row), online-softmax update, PV accumulate.
+    auto tile_compute = [&](int t, const uint4 (&kd)[4], const uint4 (&vd)[4]) {
         float s[4][G];
         bool valid[4];
 #pragma unroll
@@ -152,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
             valid[i] = (k0 + 16 * t + 4 * i + kq) < k1;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const float d = row16_sum(dot8(kc[i], qv[g])) * p.scale_log2;
+                const float d = row16_sum(dot8(kd[i], qv[g])) * p.scale_log2;
                 s[i][g] = valid[i] ? d : kNegBig;
             }
         }
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t vu[4] = {vc[i].x, vc[i].y, vc[i].z, vc[i].w};
+            const uint32_t vu[4] = {vd[i].x, vd[i].y, vd[i].z, vd[i].w};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float lo = bf16_lo(vu[w]), hi = bf16_hi(vu[w]);
@@ -184,10 +204,20 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
                 }
             }
         }
+    };
+
+    // Software pipeline over kDepth+1 register sets (statically indexed ring): the loads of
+    // the next kDepth tiles are in flight while a tile is consumed.
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            kc[i] = kn[i];
-            vc[i] = vn[i];
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nt) tile_load(kbuf[d], vbuf[d]);
+    for (int t = 0; t < nt; t += kDepth + 1) {
+#pragma unroll
+        for (int u = 0; u <= kDepth; ++u) {
+            if (t + u < nt) {
+                if (t + u + kDepth < nt) tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
+                tile_compute(t + u, kbuf[u], vbuf[u]);
+            }
         }
     }
 
@@ -238,10 +268,10 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const DecodeParams p) 
     }
 }
 
-// Combine the per-chunk partial states of one (sequence, query head): 128 threads, one per dim.
+// Combine the per-chunk partial states of one (sequence, query head): 32 threads, 4 dims each.
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int H_q) {
-    const int pair = blockIdx.x * 2 + (threadIdx.x >> 7);
-    const int d = threadIdx.x & 127;
+    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int d4 = threadIdx.x & 31;
     if (pair >= p.B * H_q) return;
     const int b = pair / H_q;
     const int hq = pair - b * H_q;
@@ -255,33 +285,49 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
     ns = ns < 1 ? 1 : ns;  // split 0 always writes a (possibly empty) state
     const float* base = p.part + ((int64_t)b * H_q + hq) * p.nsplit * kPartStride;
     float mmax = kNegBig;
+#pragma unroll 4
     for (int s = 0; s < ns; ++s) mmax = fmaxf(mmax, base[s * kPartStride + kHeadDim]);
-    float num = 0.f, den = 0.f;
+    float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+    float den = 0.f;
+#pragma unroll 4
     for (int s = 0; s < ns; ++s) {
-        const float f = __builtin_amdgcn_exp2f(base[s * kPartStride + kHeadDim] - mmax);
-        num += base[s * kPartStride + d] * f;
-        den += base[s * kPartStride + kHeadDim + 1] * f;
+        const float2 ml = *reinterpret_cast<const float2*>(base + s * kPartStride + kHeadDim);
+        const float4 a = *reinterpret_cast<const float4*>(base + s * kPartStride + 4 * d4);
+        const float f = __builtin_amdgcn_exp2f(ml.x - mmax);
+        num.x += a.x * f;
+        num.y += a.y * f;
+        num.z += a.z * f;
+        num.w += a.w * f;
+        den += ml.y * f;
     }
-    const float r = den > 0.f ? num / den : 0.f;
+    const float r = den > 0.f ? 1.0f / den : 0.f;
+    uint2 w;
+    w.x = pack_bf16(num.x * r, num.y * r);
+    w.y = pack_bf16(num.z * r, num.w * r);
     __bf16* o = reinterpret_cast<__bf16*>(p.o) + (int64_t)tq * p.o_stride_vec * 8 + hq * kHeadDim;
-    o[d] = (__bf16)r;
+    *reinterpret_cast<uint2*>(o + 4 * d4) = w;
 }
 
 // Keys per work item.  Smaller chunks give more, finer-grained waves (better balance on
 // ragged batches, more loads in flight for small batches) at the price of more partials.
 static int choose_chunk(int B, int H_kv, int max_k) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("NV_DECODE_CHUNK");
-        forced = e ? atoi(e) : 0;
-        if (forced < 0 || forced % 16 != 0) forced = 0;
-    }
-    if (forced > 0) return forced;
+    // NV_DECODE_CHUNK (multiple of 16) overrides the heuristic: a tuning aid
+    const char* e = getenv("NV_DECODE_CHUNK");
+    const int forced = e ? atoi(e) : 0;
+    if (forced > 0 && forced % 16 == 0) return forced;
+    // Fewest splits that still give the launch about NV_DEC_TARGET_WAVES waves; unsplit
+    // sequences are written directly (no partials, no merge launch).  Chunks are capped so
+    // that one long sequence in a short batch cannot become a single-wave tail.
     const long long bh = (long long)B * H_kv;
-    const long long target = 8192;  // ~2 waves per wave slot of the chip
-    int chunk = 1024;
-    while (chunk > 64 && bh * ((max_k + chunk - 1) / chunk) < target) chunk >>= 1;
-    return chunk;
+    const char* te = getenv("NV_DECODE_TARGET_WAVES");  // tuning aid
+    const long long target = te && atoi(te) > 0 ? atoi(te) : NV_DEC_TARGET_WAVES;
+    long long want = (target + bh - 1) / bh;
+    if (want < 1) want = 1;
+    long long chunk = (max_k + want - 1) / want;
+    chunk = (chunk + 63) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    if (chunk > 4096) chunk = 4096;
+    return (int)chunk;
 }
 
 static int num_splits(int max_k, int chunk) {
@@ -355,13 +401,22 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
                    (long long)workspace_bytes, (long long)need);
     }
     const int64_t items = (int64_t)B * p.nsplit * H_kv;
-    const unsigned grid = (unsigned)((items + 3) / 4);
+    const unsigned grid = (unsigned)((items + kDecWaves - 1) / kDecWaves);
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = block_size % 16 == 0 && p.chunk % 16 == 0;
-#define NV_DEC_LAUNCH(GG)                                                                          \
-    do {                                                                                           \
-        if (aligned) hipLaunchKernelGGL((attn_decode_kernel<GG, true>), dim3(grid), dim3(256), 0, st, p);  \
-        else hipLaunchKernelGGL((attn_decode_kernel<GG, false>), dim3(grid), dim3(256), 0, st, p); \
+    // Prefetch depth: one tile ahead hides HBM latency when each wave streams a long chunk
+    // and waves are scarce; with many resident waves (or G = 8, where registers are the
+    // limit) thread-level parallelism already covers it and the leaner kernel is faster.
+    const bool lean = G >= 8 || (p.nsplit == 1 && items >= NV_DEC_TARGET_WAVES);
+#define NV_DEC_LAUNCH2(GG, AL)                                                                      \
+    do {                                                                                            \
+        if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 0>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);      \
+    } while (0)
+#define NV_DEC_LAUNCH(GG)                    \
+    do {                                     \
+        if (aligned) NV_DEC_LAUNCH2(GG, true); \
+        else NV_DEC_LAUNCH2(GG, false);      \
     } while (0)
     switch (G) {
         case 1: NV_DEC_LAUNCH(1); break;
@@ -369,11 +424,12 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         case 4: NV_DEC_LAUNCH(4); break;
         default: NV_DEC_LAUNCH(8); break;
     }
+#undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH
     int rc = check_launch("nv_attn_decode_paged");
     if (rc != NV_OK) return rc;
     if (p.nsplit > 1) {
-        const unsigned mgrid = (unsigned)(((int64_t)B * H_q + 1) / 2);
+        const unsigned mgrid = (unsigned)(((int64_t)B * H_q + 7) / 8);
         hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(mgrid), dim3(256), 0, st, p, H_q);
         rc = check_launch("nv_attn_decode_paged(merge)");
     }

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Tuning aid: time the paged decode attention launch of bench.py's workload for several library
+variants (nano-vllm_amd/lib/variants/lib_*.so) and key-chunk sizes, interleaved in one process.
+
+    python tools/decode_sweep.py --chunks 0,128,256,512 --rounds 5 [--variants a,b]
+"""
+import argparse
+import glob
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from nanovllm_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chunks", default="0", help="comma list; 0 = heuristic; negative -N = heuristic with target N waves")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--variants", default="")
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--ctx-lo", type=int, default=513)
+    ap.add_argument("--ctx-hi", type=int, default=768)
+    ap.add_argument("--hq", type=int, default=16)
+    ap.add_argument("--hkv", type=int, default=8)
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
+    w = bench.Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi)
+    libs = {"default": _lib.LIB_PATH}
+    for path in sorted(glob.glob(os.path.join(ROOT, "nano-vllm_amd", "lib", "variants", "lib_*.so"))):
+        libs[os.path.basename(path)[4:-3]] = path
+    if args.variants:
+        libs = {k: v for k, v in libs.items() if k in args.variants.split(",")}
+    chunks = [int(c) for c in args.chunks.split(",")]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    results = {}
+    dlls = {name: _lib.load(path) for name, path in libs.items()}
+    for rnd in range(args.rounds + 1):
+        for name, dll in dlls.items():
+            for chunk in chunks:
+                os.environ.pop("NV_DECODE_CHUNK", None)
+                os.environ.pop("NV_DECODE_TARGET_WAVES", None)
+                if chunk > 0:
+                    os.environ["NV_DECODE_CHUNK"] = str(chunk)
+                elif chunk < 0:
+                    os.environ["NV_DECODE_TARGET_WAVES"] = str(-chunk)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for l in range(w.L):
+                    rc = dll.nv_attn_decode_paged(
+                        w.q_rot.data_ptr(), w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(), w.o.data_ptr(),
+                        w.cu_q.data_ptr(), w.cu_k.data_ptr(), w.block_tables.data_ptr(), w.B, w.block_tables.shape[1],
+                        w.max_k, w.H_Q, w.H_KV, w.D, w.NB, w.BS, w.scale, w.q_rot.stride(0), w.o.stride(0),
+                        ws.data_ptr(), ws.numel(), stream)
+                    assert rc == 0, dll.nv_last_error()
+                b.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    results.setdefault((name, chunk), []).append(a.elapsed_time(b) / w.L)
+    nbytes = w.attn_bytes_per_launch()
+    print(f"workload: B={w.B} H_q={w.H_Q} H_kv={w.H_KV} ctx {min(w.ctx)}..{max(w.ctx)} bytes/launch={nbytes}")
+    for (name, chunk), ts in sorted(results.items(), key=lambda kv: statistics.median(kv[1])):
+        med, best = statistics.median(ts), min(ts)
+        print(f"{name:>16s} chunk={chunk:4d}  median {med*1e3:8.2f} us  {nbytes/med/1e6:7.1f} GB/s   "
+              f"best {best*1e3:8.2f} us {nbytes/best/1e6:7.1f} GB/s")
+    os.environ.pop("NV_DECODE_CHUNK", None)
+    os.environ.pop("NV_DECODE_TARGET_WAVES", None)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Tuning aid: time nv_attn_prefill_varlen on a few prefill / chunked-prefill shapes and report
+algorithmic TFLOP/s (visible (query,key) pairs only, 4*D flops per pair and query head)."""
+import argparse
+import math
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from nanovllm_amd import _lib  # noqa: E402
+
+CASES = {
+    # name: (n_qs, n_ks, H_q, H_kv)
+    "cfg2_prefill_7x512": ([512] * 7, [512] * 7, 16, 8),
+    "cfg3_chunk_last_8k": ([512], [8192], 32, 8),
+    "cfg3_chunk_mid_4k": ([512], [4096], 32, 8),
+    "cfg3_7seq_chunks": ([512] * 7, [512, 1024, 2048, 4096, 8192, 6144, 3072], 32, 8),
+    "b16_n2048_h32": ([2048] * 16, [2048] * 16, 32, 8),
+    "b4_n8192_h32": ([8192] * 4, [8192] * 4, 32, 8),
+    "b16_n2048_h64": ([2048] * 16, [2048] * 16, 64, 8),
+}
+
+
+def flops(n_qs, n_ks, H_q, D=128):
+    return sum(4 * D * H_q * (nq * (nk - nq) + nq * (nq + 1) // 2) for nq, nk in zip(n_qs, n_ks))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--lib", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    dll = _lib.load(args.lib or None)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bs, D = 256, 128
+    for name in args.cases.split(","):
+        n_qs, n_ks, H_q, H_kv = CASES[name]
+        B = len(n_qs)
+        blocks = [math.ceil(n / bs) for n in n_ks]
+        NB = sum(blocks)
+        g = torch.Generator().manual_seed(0)
+        perm = torch.randperm(NB, generator=g).tolist()
+        width = max(blocks)
+        tables, nxt = [], 0
+        for nb in blocks:
+            tables.append(perm[nxt:nxt + nb] + [-1] * (width - nb))
+            nxt += nb
+        bt = torch.tensor(tables, dtype=torch.int32, device=dev)
+        cu_q = torch.tensor([0] + torch.tensor(n_qs).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+        cu_k = torch.tensor([0] + torch.tensor(n_ks).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+        T = sum(n_qs)
+        q = torch.randn(T, H_q, D, device=dev).bfloat16()
+        kc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
+        vc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
+        o = torch.empty_like(q)
+
+        def launch():
+            rc = dll.nv_attn_prefill_varlen(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), cu_q.data_ptr(),
+                                            cu_k.data_ptr(), bt.data_ptr(), B, width, max(n_qs), max(n_ks), H_q, H_kv, D,
+                                            NB, bs, D ** -0.5, q.stride(0), o.stride(0), 0, stream)
+            assert rc == 0, dll.nv_last_error()
+
+        launch()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.rounds):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(args.iters):
+                launch()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / args.iters)
+        f = flops(n_qs, n_ks, H_q)
+        med = statistics.median(ts)
+        print(f"{name:>22s}: {med*1e3:9.1f} us  {f/med/1e9:8.1f} TFLOP/s  ({100*f/med/1e9/2500:5.1f}% of 2.5 PF)  "
+              f"flops={f/1e9:.1f} G", flush=True)
+
+
+if __name__ == "__main__":
+    main()
