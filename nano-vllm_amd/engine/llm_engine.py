@@ -1,0 +1,106 @@
+"""Engine loop: add_request -> (schedule -> run -> update)* (reference: nanovllm/engine/llm_engine.py:16-175).
+
+Works on token ids; a tokenizer is optional (there is no network here to fetch one).  Metrics
+are the quantities the reference's GenerationMetrics prints (nanovllm/utils/cache_context.py:62-74):
+time to first token, mean time per output token, output tokens per second.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import torch
+
+from .model_runner import ModelRunner
+from .scheduler import Scheduler
+from .sequence import SamplingParams, Sequence
+
+
+@dataclass
+class GenerationMetrics:
+    num_prompt_tokens: int = 0
+    num_generated_tokens: int = 0
+    wall_time: float = 0.0
+    step_times: list = field(default_factory=list)          # (seconds, n_generated, decode_only)
+    first_token_time: dict = field(default_factory=dict)    # seq id -> seconds since start
+
+    def summary(self) -> dict:
+        decode = [t for t, _, only in self.step_times if only]                    # steps with decode rows only
+        decode_tokens = sum(n for _, n, only in self.step_times if only)
+        ttft = sorted(self.first_token_time.values())
+        return {
+            "prompt_tokens": self.num_prompt_tokens,
+            "generated_tokens": self.num_generated_tokens,
+            "wall_s": self.wall_time,
+            "output_tok_per_s": self.num_generated_tokens / self.wall_time if self.wall_time else 0.0,
+            "decode_steps": len(decode),
+            "decode_only_tok_per_s": decode_tokens / sum(decode) if decode else 0.0,
+            "mean_tpot_ms": 1e3 * sum(decode) / len(decode) if decode else 0.0,
+            "ttft_mean_s": sum(ttft) / len(ttft) if ttft else 0.0,
+            "ttft_max_s": ttft[-1] if ttft else 0.0,
+        }
+
+
+class LLMEngine:
+    def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
+                 max_num_batched_tokens: int = 4000, long_prefill_token_threshold: int = 512,
+                 gpu_memory_utilization: float = 0.9, device="cuda", eos: int | None = None,
+                 max_num_seqs: int | None = None, tokenizer=None):
+        self.runner = ModelRunner(model, cfg, block_size, num_kvcache_blocks, gpu_memory_utilization, device)
+        self.scheduler = Scheduler(self.runner.num_kvcache_blocks, block_size, max_num_batched_tokens,
+                                   long_prefill_token_threshold, eos if eos is not None else cfg.eos_token_id,
+                                   max_num_seqs)
+        self.tokenizer = tokenizer
+
+    def add_request(self, prompt, sampling_params: SamplingParams | None = None) -> Sequence:
+        if isinstance(prompt, str):
+            if self.tokenizer is None:
+                raise ValueError("string prompts need a tokenizer; pass token ids instead")
+            prompt = self.tokenizer.encode(prompt)
+        if not prompt:
+            raise ValueError("empty prompt")
+        seq = Sequence(prompt, sampling_params)
+        self.scheduler.add(seq)
+        return seq
+
+    def is_finished(self) -> bool:
+        return self.scheduler.is_finished()
+
+    def step(self):
+        """One schedule -> forward -> update round.
+        Returns (scheduled, sampled tokens, finished, whether the step had decode rows only)."""
+        seqs, _ = self.scheduler.schedule()
+        if not seqs:
+            raise ValueError("no sequences are scheduled")
+        decode_only = all(not s.is_prefill for s in seqs)
+        tokens = self.runner.run(seqs)
+        finished = self.scheduler.update_from_output(seqs, tokens)
+        return seqs, tokens, finished, decode_only
+
+    def generate(self, prompts, sampling_params=None):
+        """prompts: list of token-id lists (or strings with a tokenizer).  Returns (outputs, metrics);
+        outputs[i] = {"token_ids": [...], "text": str | None} in prompt order."""
+        if not isinstance(sampling_params, (list, tuple)):
+            sampling_params = [sampling_params] * len(prompts)
+        seqs = [self.add_request(p, sp) for p, sp in zip(prompts, sampling_params)]
+        metrics = GenerationMetrics(num_prompt_tokens=sum(len(s.prompt_tokens) for s in seqs))
+        cuda = self.runner.device.type == "cuda"
+        t_start = time.perf_counter()
+        while not self.is_finished():
+            t0 = time.perf_counter()
+            scheduled, tokens, _, decode_only = self.step()
+            if cuda:
+                torch.cuda.synchronize(self.runner.device)
+            now = time.perf_counter()
+            n_gen = sum(t is not None for t in tokens)
+            metrics.step_times.append((now - t0, n_gen, decode_only))
+            for s, t in zip(scheduled, tokens):
+                if t is not None and len(s.output_tokens) == 1:
+                    metrics.first_token_time[s.id] = now - t_start
+            metrics.num_generated_tokens += n_gen
+        metrics.wall_time = time.perf_counter() - t_start
+        outs = []
+        for s in seqs:
+            text = self.tokenizer.decode(s.output_tokens) if self.tokenizer is not None else None
+            outs.append({"token_ids": list(s.output_tokens), "text": text})
+        return outs, metrics

@@ -1,0 +1,135 @@
+"""Builds the flat per-step inputs and the CacheContext, owns the KV cache, runs the model, samples.
+
+Metadata integers follow the reference's ModelRunner._prepare_inputs / _prepare_block_tables /
+get_slot_mapping exactly (nanovllm/engine/model_runner.py:39-148): prefill rows take
+prompt[computed : computed+scheduled] at positions computed..; decode rows take the last sampled
+token at position num_tokens-1 with the slot of logical position `num_computed`; slot =
+block_table[p // bs] * bs + p % bs; seqlen_q = scheduled, seqlen_k = computed + scheduled; block
+tables are right-padded with -1.  They are built with numpy in one pass (the reference loops per
+token and round-trips through the device, model_runner.py:140-148).  The cache has the reference's
+layout [2, L, num_blocks, block_size, H_kv, D] (:175-184) and its per-layer views are bound to every
+module that has `k_cache` and `v_cache` attributes (:186-192); the number of blocks is sized from
+free device memory (the formula the reference left commented out at :171) unless given.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ..utils.cache_context import CacheContext, set_context
+from .sequence import Sequence
+
+
+def prepare_inputs(seqs: list[Sequence], block_size: int) -> dict:
+    """Pure host part: python ints / numpy arrays for one step (see module docstring)."""
+    ids, pos, slots = [], [], []
+    n_q = np.empty(len(seqs), dtype=np.int64)
+    n_k = np.empty(len(seqs), dtype=np.int64)
+    width = max(len(s.block_table) for s in seqs)
+    tables = np.full((len(seqs), width), -1, dtype=np.int32)
+    n_decode = 0
+    for i, seq in enumerate(seqs):
+        table = np.asarray(seq.block_table, dtype=np.int64)
+        tables[i, :len(table)] = table
+        start = seq.num_computed_tokens
+        if seq.is_prefill:
+            end = start + seq.num_scheduled_tokens
+            p = np.arange(start, end, dtype=np.int64)
+            ids.append(np.asarray(seq.prompt_tokens[start:end], dtype=np.int64))
+            pos.append(p)
+        else:
+            p = np.array([start], dtype=np.int64)                 # slot of logical position `computed`
+            ids.append(np.array([seq.output_tokens[-1]], dtype=np.int64))
+            pos.append(np.array([len(seq) - 1], dtype=np.int64))
+        slots.append(table[p // block_size] * block_size + p % block_size)
+        n_q[i] = seq.num_scheduled_tokens
+        n_k[i] = seq.num_computed_tokens + seq.num_scheduled_tokens
+        n_decode += int(seq.num_scheduled_tokens == 1)
+    cu_q = np.zeros(len(seqs) + 1, dtype=np.int32)
+    cu_k = np.zeros(len(seqs) + 1, dtype=np.int32)
+    np.cumsum(n_q, out=cu_q[1:])
+    np.cumsum(n_k, out=cu_k[1:])
+    return dict(input_ids=np.concatenate(ids), positions=np.concatenate(pos),
+                slot_mapping=np.concatenate(slots).astype(np.int32), cu_seqlens_q=cu_q, cu_seqlens_k=cu_k,
+                max_seqlen_q=int(n_q.max()), max_seqlen_k=int(n_k.max()), block_tables=tables,
+                num_decode_seqs=n_decode)
+
+
+class ModelRunner:
+    def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
+                 gpu_memory_utilization: float = 0.9, device: str | torch.device = "cuda",
+                 dtype: torch.dtype = torch.bfloat16):
+        self.model, self.cfg, self.block_size = model, cfg, block_size
+        self.device, self.dtype = torch.device(device), dtype
+        self.kv_cache: torch.Tensor | None = None
+        self.num_kvcache_blocks = self.init_kv_cache(num_kvcache_blocks, gpu_memory_utilization)
+
+    # ---- KV cache -------------------------------------------------------------------------
+    def block_bytes(self) -> int:
+        c = self.cfg
+        return 2 * c.num_hidden_layers * self.block_size * c.num_key_value_heads * c.head_dim * self.dtype.itemsize
+
+    def init_kv_cache(self, num_blocks: int | None, utilization: float) -> int:
+        c = self.cfg
+        if num_blocks is None:
+            if self.device.type != "cuda":
+                raise ValueError("num_kvcache_blocks must be given when not running on a GPU")
+            free, total = torch.cuda.mem_get_info(self.device)
+            budget = int(total * utilization) - (total - free)
+            num_blocks = budget // self.block_bytes()
+        assert num_blocks > 0, "no memory left for the KV cache"
+        self.kv_cache = torch.empty(2, c.num_hidden_layers, num_blocks, self.block_size, c.num_key_value_heads,
+                                    c.head_dim, dtype=self.dtype, device=self.device)
+        layer = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):
+                module.k_cache = self.kv_cache[0][layer]
+                module.v_cache = self.kv_cache[1][layer]
+                layer += 1
+        assert layer == c.num_hidden_layers, f"bound {layer} attention layers, expected {c.num_hidden_layers}"
+        return num_blocks
+
+    # ---- one step -------------------------------------------------------------------------
+    def _to_device(self, arr: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(arr)
+        if self.device.type == "cuda":
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t
+
+    def set_step_context(self, seqs: list[Sequence]):
+        m = prepare_inputs(seqs, self.block_size)
+        ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self._to_device(m["slot_mapping"]),
+                           cu_seqlens_q=self._to_device(m["cu_seqlens_q"]),
+                           cu_seqlens_k=self._to_device(m["cu_seqlens_k"]), max_seqlen_q=m["max_seqlen_q"],
+                           max_seqlen_k=m["max_seqlen_k"], block_tables=self._to_device(m["block_tables"]),
+                           block_size=self.block_size, num_decode_seqs=m["num_decode_seqs"])
+        set_context(ctx)
+        return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
+
+    @torch.inference_mode()
+    def run(self, seqs: list[Sequence]) -> list[int | None]:
+        """Forward the scheduled tokens; returns one sampled token per sequence, or None while a
+        sequence's prompt is still being chunked (model_runner.py:214-240)."""
+        input_ids, positions, m = self.set_step_context(seqs)
+        last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)
+        logits = self.model(input_ids, positions, logits_rows=last_rows)          # [B, vocab]
+        temps = [s.sampling_params.temperature for s in seqs]
+        tokens = sample(logits, temps).tolist()
+        out = []
+        for seq, tok in zip(seqs, tokens):
+            complete = seq.num_computed_tokens + seq.num_scheduled_tokens >= len(seq.prompt_tokens)
+            out.append(tok if complete else None)
+        return out
+
+
+def sample(logits: torch.Tensor, temperatures: list[float]) -> torch.Tensor:
+    """temperature == 0 -> argmax; otherwise softmax(logits / T) + multinomial
+    (nanovllm/utils/sampler.py:25-34)."""
+    greedy = logits.argmax(dim=-1)
+    if all(t == 0 for t in temperatures):
+        return greedy
+    t = torch.tensor([x if x > 0 else 1.0 for x in temperatures], dtype=torch.float32, device=logits.device)
+    probs = torch.softmax(logits.float() / t.unsqueeze(1), dim=-1)
+    drawn = torch.multinomial(probs, num_samples=1).squeeze(1)
+    is_greedy = torch.tensor([x == 0 for x in temperatures], device=logits.device)
+    return torch.where(is_greedy, greedy, drawn)

@@ -1,0 +1,103 @@
+"""Continuous-batching scheduler with chunked prefill (host Python).
+
+Policy of the reference's nanovllm/engine/scheduler.py:30-160: running sequences first (a decode
+token, or the next prompt chunk of at most `long_prefill_token_threshold` tokens), then waiting
+sequences while the token budget `max_num_batched_tokens` lasts; admission looks up the prefix
+cache and allocates blocks for the first chunk only; a sequence finishes on `max_tokens` or EOS and
+its blocks are released.  A running sequence that cannot get a block is left out of the step (the
+reference prints and drops it from the queue, scheduler.py:52-57); `max_num_seqs` is enforced only
+when set (the reference stores it and never reads it).
+"""
+from __future__ import annotations
+
+from collections import deque
+
+from .block_manager import BlockManager
+from .sequence import Sequence, SequenceStatus
+
+
+class Scheduler:
+    def __init__(self, num_kvcache_blocks: int, kvcache_block_size: int = 256, max_num_batched_tokens: int = 4000,
+                 long_prefill_token_threshold: int = 512, eos: int | None = None, max_num_seqs: int | None = None):
+        self.block_size = kvcache_block_size
+        self.max_scheduled_tokens = max_num_batched_tokens
+        self.long_prefill_token_threshold = long_prefill_token_threshold
+        self.eos = eos
+        self.max_num_seqs = max_num_seqs
+        self.block_manager = BlockManager(num_kvcache_blocks, kvcache_block_size)
+        self.waiting: deque[Sequence] = deque()
+        self.running: deque[Sequence] = deque()
+
+    def add(self, seq: Sequence) -> None:
+        seq.status = SequenceStatus.WAITING
+        self.waiting.append(seq)
+
+    def is_finished(self) -> bool:
+        return not self.waiting and not self.running
+
+    def schedule(self) -> tuple[list[Sequence], bool]:
+        """Returns (scheduled sequences in batch order, whether any new sequence was admitted)."""
+        bm = self.block_manager
+        budget = self.max_scheduled_tokens
+        scheduled: list[Sequence] = []
+        # 1. running sequences: decode token or next prompt chunk
+        for seq in self.running:
+            seq.num_scheduled_tokens = 0
+            if budget <= 0 or seq.is_finished:
+                continue
+            remaining = len(seq.prompt_tokens) - seq.num_computed_tokens
+            n_new = min(remaining, self.long_prefill_token_threshold, budget) if remaining > 0 else 1
+            try:
+                bm.append_slots(seq, n_new)
+            except ValueError:
+                continue                       # no block available: sits this step out
+            seq.num_scheduled_tokens = n_new
+            bm.publish_full_blocks(seq, seq.num_computed_tokens + n_new)
+            budget -= n_new
+            scheduled.append(seq)
+        # 2. admit waiting sequences
+        admitted = 0
+        while self.waiting and budget > 0:
+            if self.max_num_seqs is not None and len(self.running) >= self.max_num_seqs:
+                break
+            seq = self.waiting[0]
+            cached_blocks, n_cached = bm.get_computed_blocks(seq.prompt_tokens)
+            n_new = len(seq.prompt_tokens) - n_cached
+            if 0 < self.long_prefill_token_threshold < n_new:
+                n_new = self.long_prefill_token_threshold
+            n_new = min(n_new, budget)
+            # blocks for tokens [n_cached, n_cached + n_new); n_cached is block aligned
+            blocks_needed = -(-n_new // self.block_size)
+            idle_hits = sum(1 for b in cached_blocks if bm.block_pool[b].ref_count == 0)
+            if not bm.can_allocate(blocks_needed + idle_hits):
+                break
+            bm.allocate_slots(seq, cached_blocks, blocks_needed)
+            seq.num_computed_tokens = n_cached
+            seq.num_scheduled_tokens = n_new
+            seq.status = SequenceStatus.RUNNING
+            bm.publish_full_blocks(seq, n_cached + n_new)
+            budget -= n_new
+            self.waiting.popleft()
+            self.running.append(seq)
+            scheduled.append(seq)
+            admitted += 1
+        return scheduled, admitted > 0
+
+    def update_from_output(self, seqs: list[Sequence], token_ids: list[int | None]) -> list[Sequence]:
+        """Account the step: advance computed counts, append sampled tokens (None = prompt not yet
+        complete), finish and free.  Returns the sequences that finished."""
+        finished = []
+        for seq, token_id in zip(seqs, token_ids):
+            seq.num_computed_tokens += seq.num_scheduled_tokens
+            seq.num_scheduled_tokens = 0
+            if token_id is not None:
+                seq.add_token(token_id)
+                if len(seq.output_tokens) >= seq.sampling_params.max_tokens or token_id == self.eos:
+                    seq.status = SequenceStatus.FINISHED
+                    finished.append(seq)
+        if finished:
+            for seq in finished:
+                self.block_manager.free_sequence(seq.id)
+                seq.block_table = []
+            self.running = deque(s for s in self.running if not s.is_finished)
+        return finished

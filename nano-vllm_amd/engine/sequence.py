@@ -1,0 +1,67 @@
+"""Per-request host state (plain Python; mirrors the fields of the reference's
+nanovllm/engine/sequence.py:11-72 that the scheduler, block manager and runner read)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from enum import Enum
+from itertools import count
+
+
+@dataclass
+class SamplingParams:
+    """nanovllm/sampling_params.py:3-6.  temperature == 0 selects argmax decoding (the reference's
+    sampler rejects it, nanovllm/utils/sampler.py:20-22)."""
+    temperature: float = 1.0
+    max_tokens: int = 256
+
+
+class SequenceStatus(Enum):
+    WAITING = "waiting"
+    RUNNING = "running"
+    FINISHED = "finished"
+
+
+class Sequence:
+    _ids = count()
+
+    def __init__(self, prompt_tokens: list[int], sampling_params: SamplingParams | None = None):
+        self.id = f"seq_{next(Sequence._ids)}"
+        self.status = SequenceStatus.WAITING
+        self.prompt_tokens = list(prompt_tokens)
+        self.output_tokens: list[int] = []
+        self.num_computed_tokens = 0      # tokens whose K/V is in the cache
+        self.num_scheduled_tokens = 0     # tokens to process in the coming step
+        self.block_table: list[int] = []  # physical block ids, logical order
+        self.sampling_params = sampling_params or SamplingParams()
+
+    def __len__(self) -> int:
+        return len(self.prompt_tokens) + len(self.output_tokens)
+
+    num_tokens = property(__len__)
+
+    @property
+    def is_finished(self) -> bool:
+        return self.status == SequenceStatus.FINISHED
+
+    @property
+    def is_prefill(self) -> bool:
+        """No sampled token yet (sequence.py:45-49)."""
+        return not self.output_tokens
+
+    @property
+    def last_token(self) -> int:
+        return self.output_tokens[-1] if self.output_tokens else self.prompt_tokens[-1]
+
+    @property
+    def token_ids(self) -> list[int]:
+        return self.prompt_tokens + self.output_tokens
+
+    def token_at(self, pos: int) -> int:
+        n = len(self.prompt_tokens)
+        return self.prompt_tokens[pos] if pos < n else self.output_tokens[pos - n]
+
+    def add_token(self, token_id: int) -> None:
+        self.output_tokens.append(token_id)
+
+    def __repr__(self) -> str:
+        return f"Sequence({self.id}, {self.status.value}, tokens={len(self)}, blocks={len(self.block_table)})"

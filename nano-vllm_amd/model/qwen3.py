@@ -1,0 +1,185 @@
+"""Qwen3-shaped decoder used as the caller harness of the attention hot path.
+
+Same module tree and HF parameter names as the reference's nanovllm/model/qwen3.py:10-229
+(`model.layers.N.self_attn.{q,k,v,o}_proj`, `.q_norm`, `.k_norm`, `input_layernorm`,
+`post_attention_layernorm`, `model.norm`, `lm_head`, tied embeddings), same pre-norm residual
+threading (:148-172).  The GEMMs, the embedding and SwiGLU stay plain torch ops (out of scope of
+the hand-written path).  Two differences in wiring:
+  * the attention block can run the chain q_norm -> k_norm -> rope -> store_kvcache as ONE HIP
+    launch (`nv_qknorm_rope_store`) followed by `Attention.attend`; `fused=False` keeps the
+    reference's module-by-module order (:62-75);
+  * `layers` selects where Attention / RMSNorm / get_rope come from.  The default is this package's
+    HIP-backed modules; tests pass a module with CPU stand-ins to exercise the host plumbing.
+Models without q/k-norm (Llama-style) set `qk_norm=False`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..utils.cache_context import get_context
+
+
+@dataclass
+class ModelConfig:
+    vocab_size: int = 151936
+    hidden_size: int = 1024
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 28
+    num_attention_heads: int = 16
+    num_key_value_heads: int = 8
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_position_embeddings: int = 40960
+    tie_word_embeddings: bool = True
+    attention_bias: bool = False
+    qk_norm: bool = True
+    rope_scaling: dict | None = None
+    eos_token_id: int | None = None
+
+    @classmethod
+    def qwen3_0_6b(cls, **kw):
+        return cls(**kw)
+
+    @classmethod
+    def qwen3_8b(cls, **kw):
+        return cls(hidden_size=4096, intermediate_size=12288, num_hidden_layers=36, num_attention_heads=32,
+                   tie_word_embeddings=False, **kw)
+
+    @classmethod
+    def qwen3_32b(cls, **kw):
+        return cls(hidden_size=5120, intermediate_size=25600, num_hidden_layers=64, num_attention_heads=64,
+                   tie_word_embeddings=False, **kw)
+
+    @classmethod
+    def llama31_8b(cls, **kw):
+        return cls(vocab_size=128256, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                   num_attention_heads=32, rope_theta=5e5, max_position_embeddings=131072, rms_norm_eps=1e-5,
+                   tie_word_embeddings=False, qk_norm=False,
+                   rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                                     original_max_position_embeddings=8192), **kw)
+
+
+def _default_layers():
+    from .. import layers as _pkg  # noqa: F401
+    from ..layers import attention, layernorm, rope
+
+    class _L:
+        Attention = attention.Attention
+        RMSNorm = layernorm.RMSNorm
+        make_rope = staticmethod(rope.make_rope)
+        fused_qknorm_rope_store = staticmethod(_hip_fused)
+    return _L
+
+
+def _hip_fused(positions, q, k, v, q_w, k_w, rope, eps, attn):
+    """q_norm + k_norm + rope + KV scatter in one launch; returns the rotated q."""
+    from .. import ops
+    ctx = get_context()
+    q_out, _ = ops.qknorm_rope_store(positions, q, k, v, q_w, k_w, rope.cos_sin_cache, eps, ctx.slot_mapping,
+                                     attn.k_cache, attn.v_cache, want_k=False)
+    return q_out
+
+
+class Qwen3Attention(nn.Module):
+    def __init__(self, cfg: ModelConfig, L, fused: bool):
+        super().__init__()
+        self.num_heads, self.num_kv_heads, self.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
+        self.eps = cfg.rms_norm_eps
+        self.q_proj = nn.Linear(cfg.hidden_size, self.q_size, bias=cfg.attention_bias)
+        self.k_proj = nn.Linear(cfg.hidden_size, self.kv_size, bias=cfg.attention_bias)
+        self.v_proj = nn.Linear(cfg.hidden_size, self.kv_size, bias=cfg.attention_bias)
+        self.o_proj = nn.Linear(self.q_size, cfg.hidden_size, bias=cfg.attention_bias)
+        self.rope = L.make_rope(self.head_dim, cfg.max_position_embeddings, cfg.rope_theta, cfg.rope_scaling)
+        self.qk_norm = cfg.qk_norm
+        if cfg.qk_norm:
+            self.q_norm = L.RMSNorm(self.head_dim, cfg.rms_norm_eps)
+            self.k_norm = L.RMSNorm(self.head_dim, cfg.rms_norm_eps)
+        self.attention = L.Attention(self.num_heads, self.head_dim, self.num_kv_heads, self.head_dim ** -0.5,
+                                     cfg.max_position_embeddings)
+        self._fused = L.fused_qknorm_rope_store if fused else None
+
+    def forward(self, x: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        q = self.q_proj(x).view(-1, self.num_heads, self.head_dim)
+        k = self.k_proj(x).view(-1, self.num_kv_heads, self.head_dim)
+        v = self.v_proj(x).view(-1, self.num_kv_heads, self.head_dim)
+        if self._fused is not None:
+            q = self._fused(positions, q, k, v, self.q_norm.weight if self.qk_norm else None,
+                            self.k_norm.weight if self.qk_norm else None, self.rope, self.eps, self.attention)
+            o = self.attention.attend(q)
+        else:
+            if self.qk_norm:
+                q, k = self.q_norm(q), self.k_norm(k)
+            q, k = self.rope(positions, q, k)
+            o = self.attention(q, k, v)
+        return self.o_proj(o.reshape(-1, self.q_size))
+
+
+class Qwen3MLP(nn.Module):
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class Qwen3DecoderLayer(nn.Module):
+    def __init__(self, cfg: ModelConfig, L, fused: bool):
+        super().__init__()
+        self.self_attn = Qwen3Attention(cfg, L, fused)
+        self.mlp = Qwen3MLP(cfg)
+        self.input_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, positions, hidden, residual):
+        if residual is None:
+            residual = hidden
+            hidden = self.input_layernorm(hidden)
+        else:
+            hidden, residual = self.input_layernorm(hidden, residual)
+        hidden = self.self_attn(hidden, positions)
+        hidden, residual = self.post_attention_layernorm(hidden, residual)
+        return self.mlp(hidden), residual
+
+
+class Qwen3Model(nn.Module):
+    def __init__(self, cfg: ModelConfig, L, fused: bool):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, L, fused) for _ in range(cfg.num_hidden_layers))
+        self.norm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, input_ids, positions):
+        hidden, residual = self.embed_tokens(input_ids), None
+        ctx = get_context()
+        for idx, layer in enumerate(self.layers):
+            ctx.layer_idx = idx
+            hidden, residual = layer(positions, hidden, residual)
+        hidden, _ = self.norm(hidden, residual)
+        return hidden
+
+
+class Qwen3ForCausalLM(nn.Module):
+    def __init__(self, cfg: ModelConfig, layers=None, fused: bool = True):
+        super().__init__()
+        L = layers if layers is not None else _default_layers()
+        self.config = cfg
+        self.model = Qwen3Model(cfg, L, fused and hasattr(L, "fused_qknorm_rope_store"))
+        self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+        if cfg.tie_word_embeddings:
+            self.lm_head.weight = self.model.embed_tokens.weight
+
+    def forward(self, input_ids, positions, logits_rows=None):
+        """logits_rows: optional index tensor; when given only those token rows go through lm_head."""
+        hidden = self.model(input_ids, positions)
+        if logits_rows is not None:
+            hidden = hidden[logits_rows]
+        return self.lm_head(hidden)

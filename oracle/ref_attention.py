@@ -30,7 +30,7 @@ def store_kvcache_ref(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v
 def gather_kv(cache: torch.Tensor, block_table_row: torch.Tensor, n_k: int) -> torch.Tensor:
     """Keys 0..n_k-1 of one sequence: key j lives at cache[block_table[j // bs], j % bs]."""
     bs = cache.shape[1]
-    j = torch.arange(n_k)
+    j = torch.arange(n_k, device=cache.device)
     blocks = block_table_row.long()[j // bs]
     return cache[blocks, j % bs]                        # [n_k, H_kv, D]
 
@@ -42,7 +42,8 @@ def paged_attention_ref(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
     T, H_q, D = q.shape
     H_kv = k_cache.shape[2]
     G = H_q // H_kv
-    out = torch.zeros(T, H_q, D, dtype=torch.float32)
+    dev = q.device
+    out = torch.zeros(T, H_q, D, dtype=torch.float32, device=dev)
     cq = cu_seqlens_q.tolist()
     ck = cu_seqlens_k.tolist()
     for b in range(len(cq) - 1):
@@ -57,13 +58,13 @@ def paged_attention_ref(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
         vb = vb.repeat_interleave(G, dim=1).transpose(0, 1)
         s = torch.matmul(qb, kb.transpose(1, 2)) * scale                      # [H_q, n_q, n_k]
         if causal:
-            i = torch.arange(n_q).unsqueeze(1)
-            j = torch.arange(n_k).unsqueeze(0)
+            i = torch.arange(n_q, device=dev).unsqueeze(1)
+            j = torch.arange(n_k, device=dev).unsqueeze(0)
             visible = j <= i + (n_k - n_q)
             s = s.masked_fill(~visible, float("-inf"))
             dead = ~visible.any(dim=1)                                        # rows seeing nothing
         else:
-            dead = torch.zeros(n_q, dtype=torch.bool)
+            dead = torch.zeros(n_q, dtype=torch.bool, device=dev)
         s[:, dead, :] = 0.0
         p = torch.softmax(s, dim=-1)
         o = torch.matmul(p, vb)                                               # [H_q, n_q, D]
