@@ -65,9 +65,19 @@ class RotaryPositionEmbedding(nn.Module):
         assert rotary_dim % 2 == 0, "dimension should be even in RotaryPositionEmbedding"
         self.head_size = head_size
         self.rotary_dim = rotary_dim
+        self._table_args = (rotary_dim, max_seq_len, base, rope_scaling)
         self.register_buffer("cos_sin_cache",
                              build_cos_sin_cache(rotary_dim, max_seq_len, base, device, rope_scaling),
                              persistent=False)
+
+    def _apply(self, fn, recurse=True):
+        """The table stays fp32 whatever dtype the surrounding model is cast to (`model.to(bf16)`
+        would otherwise round it): after a dtype-changing cast it is rebuilt on the new device."""
+        super()._apply(fn, recurse)
+        if self.cos_sin_cache.dtype != torch.float32:
+            d, n, base, scaling = self._table_args
+            self.cos_sin_cache = build_cos_sin_cache(d, n, base, None, scaling).to(self.cos_sin_cache.device)
+        return self
 
     def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):
         return ops.rope(positions, query, key, self.cos_sin_cache)
