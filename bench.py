@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--attn-only", action="store_true", help="step = decode attention launches only")
+    ap.add_argument("--tp-layers", type=int, default=8, help="layers in the head-sharded sub-benchmark")
+    ap.add_argument("--no-tp", action="store_true", help="skip the head-sharded sub-benchmark")
     return ap.parse_args()
 
 
@@ -165,11 +167,10 @@ def run_step(plan, events=None):
             _lib.check(rc, fn.__name__)
 
 
-def cpu_baseline(w: Workload, seconds: float):
-    """The CPU oracle on one layer's cache, sequence by sequence, for about `seconds`."""
+def cpu_baseline(w: Workload, kc: torch.Tensor, vc: torch.Tensor, seconds: float):
+    """The CPU oracle on one layer's cache (host copies kc, vc), sequence by sequence, for about `seconds`."""
     from oracle.ref_attention import paged_attention_ref
     threads = torch.get_num_threads()
-    kc, vc = w.kv_cache[0, 0].cpu(), w.kv_cache[1, 0].cpu()
     q = torch.randn(w.B, w.H_Q, w.D).bfloat16()
     bt, ctx = w.block_tables.cpu(), w.ctx
     done_bytes, done_seqs = 0, 0
@@ -186,6 +187,78 @@ def cpu_baseline(w: Workload, seconds: float):
     return {"value": round(done_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": threads, "kind": "port",
             "sample": f"oracle decode attention, 1 layer, {done_seqs} sequences of the same batch "
                       f"(ctx {min(ctx)}..{max(ctx)}), {dt:.1f} s, torch fp32 on {threads} threads"}
+
+
+def tp_bench(args, dev, rank, world, dist):
+    """Head-sharded decode attention + all-gather of head outputs (BASELINE config 4 shapes:
+    Qwen3-32B attention, H_q=64, H_kv=8, D=128, batch 256, ctx 2048, block 256).  Rank r holds kv heads
+    [r*8/N, (r+1)*8/N) of every layer's cache; metadata is replicated; per layer: local decode
+    attention, then one all-gather [T, H_q/N, D] -> [T, H_q, D].  `layers` is reduced from the
+    model's 64 to bound memory and time; per-layer work is what is reported."""
+    from nanovllm_amd import _lib
+    from nanovllm_amd.parallel import HeadShard, all_gather_heads
+    H_Q, H_KV, D, BS, B, CTX, L = 64, 8, 128, 256, 256, 2048, args.tp_layers
+    shard = HeadShard(rank, world, H_Q, H_KV)
+    hq, hkv = shard.local_heads, shard.local_kv_heads
+    g = torch.Generator().manual_seed(1234)                      # same tables on every rank
+    nb_seq = CTX // BS
+    NB = B * nb_seq
+    perm = torch.randperm(NB, generator=g)
+    bt = perm.view(B, nb_seq).to(torch.int32).to(dev)
+    cu_k = (torch.arange(B + 1, dtype=torch.int32) * CTX).to(dev)
+    cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    cache = torch.empty(2, L, NB, BS, hkv, D, dtype=torch.bfloat16, device=dev)
+    for l in range(L):
+        cache[0, l].normal_()
+        cache[1, l].normal_()
+    q = torch.randn(B, hq, D, device=dev).bfloat16()
+    o_local = torch.empty_like(q)
+    o_full = torch.empty(B, H_Q, D, dtype=torch.bfloat16, device=dev)
+    staging = torch.empty(world * B, hq, D, dtype=torch.bfloat16, device=dev)
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = torch.empty(max(dll.nv_attn_decode_workspace_bytes(B, hq, hkv, D, CTX), 16), dtype=torch.uint8, device=dev)
+
+    def step(gather):
+        for l in range(L):
+            rc = dll.nv_attn_decode_paged(q.data_ptr(), cache[0, l].data_ptr(), cache[1, l].data_ptr(), o_local.data_ptr(),
+                                          cu_q.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B, nb_seq, CTX, hq, hkv, D,
+                                          NB, BS, D ** -0.5, q.stride(0), o_local.stride(0), ws.data_ptr(), ws.numel(),
+                                          stream)
+            if rc != 0:
+                _lib.check(rc, "nv_attn_decode_paged")
+            if gather:
+                all_gather_heads(o_local, shard, out=o_full, staging=staging)
+
+    def timed(gather):
+        for _ in range(2):
+            step(gather)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt / args.steps
+
+    t_attn = timed(False)
+    t_full = timed(world > 1)
+    bytes_layer_all = B * (2 * CTX * H_KV * D * 2 + 2 * H_Q * D * 2 + 4 * nb_seq + 8)     # all ranks together
+    return {"workload": f"Qwen3-32B attention shapes, decode batch {B}, ctx {CTX}, block {BS}, {L} layers, "
+                        f"kv heads sharded {H_KV}/{world} per GPU, RCCL all-gather of o per layer",
+            "ms_per_layer_attn_only": round(t_attn / L * 1e3, 4),
+            "ms_per_layer_with_allgather": round(t_full / L * 1e3, 4),
+            "attn_GBps_all_gpus": round(bytes_layer_all * L / t_full / 1e9, 1),
+            "allgather_bytes_per_layer": B * H_Q * D * 2,
+            "tok_per_s_attention_path": round(B / (t_full / L * 64), 1)}
 
 
 def main():
@@ -241,6 +314,13 @@ def main():
     attn_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     achieved = w.attn_bytes_per_launch() / (attn_ms * 1e-3) / 1e9
 
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    cpu_kv = (w.kv_cache[0, 0].cpu(), w.kv_cache[1, 0].cpu()) if want_cpu else None
+    del plan
+    w.kv_cache = None
+    torch.cuda.empty_cache()
+    tp = None if args.no_tp else tp_bench(args, dev, rank, world, dist)
+
     if rank == 0:
         traffic = None
         tf = os.path.join(ROOT, "profiles", "decode_traffic.json")
@@ -266,8 +346,10 @@ def main():
                          "traffic": traffic, "launch_ms": round(attn_ms, 5),
                          "algorithmic_bytes_per_launch": w.attn_bytes_per_launch()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        if tp is not None:
+            out["head_sharded"] = tp
+        if want_cpu:
+            out["cpu_baseline"] = cpu_baseline(w, cpu_kv[0], cpu_kv[1], args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
