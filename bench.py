@@ -189,6 +189,15 @@ def cpu_baseline(w: Workload, kc: torch.Tensor, vc: torch.Tensor, seconds: float
                       f"(ctx {min(ctx)}..{max(ctx)}), {dt:.1f} s, torch fp32 on {threads} threads"}
 
 
+def reduce_scalar(dist, dev, value: float, op: str) -> float:
+    """MAX / SUM of a python float over the ranks (CUDA tensor for RCCL, host tensor for gloo)."""
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t.item()
+
+
 def tp_bench(args, dev, rank, world, dist):
     """Head-sharded decode attention + all-gather of head outputs (BASELINE config 4 shapes:
     Qwen3-32B attention, H_q=64, H_kv=8, D=128, batch 256, ctx 2048, block 256).  Rank r holds kv heads
@@ -218,6 +227,7 @@ def tp_bench(args, dev, rank, world, dist):
     dll = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = torch.empty(max(dll.nv_attn_decode_workspace_bytes(B, hq, hkv, D, CTX), 16), dtype=torch.uint8, device=dev)
+    gloo = dist is not None and dist.get_backend() == "gloo"
 
     def step(gather):
         for l in range(L):
@@ -227,7 +237,9 @@ def tp_bench(args, dev, rank, world, dist):
                                           stream)
             if rc != 0:
                 _lib.check(rc, "nv_attn_decode_paged")
-            if gather:
+            if gather and gloo:          # rehearsal only: gloo gathers host tensors
+                o_full.copy_(all_gather_heads(o_local.cpu(), shard))
+            elif gather:
                 all_gather_heads(o_local, shard, out=o_full, staging=staging)
 
     def timed(gather):
@@ -242,12 +254,7 @@ def tp_bench(args, dev, rank, world, dist):
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = t.item()
-        return dt / args.steps
+        return reduce_scalar(dist, dev, time.perf_counter() - t0, "max") / args.steps
 
     t_attn = timed(False)
     t_full = timed(world > 1)
@@ -273,13 +280,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal aid for boxes with fewer GPUs than ranks: NV_BENCH_SHARE_GPU=1 puts every rank on
+    # cuda:0 and uses gloo (RCCL refuses two ranks on one device).  Never used for reported numbers.
+    share = os.environ.get("NV_BENCH_SHARE_GPU") == "1"
+    dev = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            import datetime
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w = Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi, seed=rank)
     plan = w.build_plan(args.attn_only)
@@ -298,16 +312,8 @@ def main():
     for _ in range(args.steps):
         run_step(plan, events)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-        tot = torch.tensor([float(w.step_bytes(args.attn_only))], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot)
-        step_bytes_all = tot.item()
-    else:
-        step_bytes_all = float(w.step_bytes(args.attn_only))
+    elapsed = reduce_scalar(dist, dev, time.perf_counter() - t0, "max")
+    step_bytes_all = reduce_scalar(dist, dev, float(w.step_bytes(args.attn_only)), "sum")
 
     ms_per_step = elapsed / args.steps * 1e3
     value = step_bytes_all / (elapsed / args.steps) / 1e9
@@ -338,7 +344,8 @@ def main():
                                    + ("decode attention only" if args.attn_only else
                                       "2x add+RMSNorm, fused qk-norm+RoPE+KV store, paged decode attention per layer"),
                        "H_q": 16, "H_kv": 8, "head_dim": 128, "batch": args.batch, "layers": args.layers,
-                       "parallelism": "single GPU" if world == 1 else f"dp{world} replicas"},
+                       "parallelism": "single GPU" if world == 1 else f"dp{world} replicas"
+                                      + (" (REHEARSAL: ranks share one GPU, gloo)" if share else "")},
             "pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "hot_path_tok_per_s": round(args.batch * world / (ms_per_step * 1e-3), 1),
             "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (+merge)", "achieved": round(achieved, 1),
