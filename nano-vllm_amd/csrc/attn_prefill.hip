@@ -1,14 +1,21 @@
 // Varlen prefill / chunked-prefill attention over the paged KV cache for gfx950.
 //
-// Flash-style: one workgroup (4 waves) owns a 128-row query tile of one (sequence, query
-// head); each wave owns 32 query rows.  K/V tiles of 64 keys are gathered through the
-// block table into a double-buffered, swizzled LDS image by LDS-DMA and consumed by
-// bf16 MFMA 32x32x16:
+// Flash-style bf16 MFMA kernel.  A workgroup is 4 waves; each wave owns 32 query rows of one
+// query head.  The waves of a workgroup share one kv head: they are the `hpw` = gcd(G, 4)
+// query heads of a GQA group times 4/hpw consecutive 32-row blocks, so a K/V tile staged in
+// LDS once serves up to 4 query heads.  K/V tiles of 64 keys are gathered through the block
+// table into a double-buffered, swizzled LDS image by LDS-DMA and consumed by
+// v_mfma_f32_32x32x16_bf16:
 //   S^T = K . Q^T      (A = K rows from LDS via ds_read_b128, B = Q fragments in registers)
 //   O^T += V^T . P^T   (A = V^T via ds_read_b64_tr_b16 transposed reads, B = P^T taken
 //                       straight from the S^T accumulator registers, converted to bf16)
-// With the "swapped" product the 32 scores of a query row live in the registers of two
-// lanes (l, l^32), so the online softmax needs one cross-lane exchange per tile.
+// With the "swapped" product the 64 scores of a query row live in the registers of two
+// lanes (l, l^32), so the online softmax needs one cross-lane exchange per tile.  The
+// running maximum is only raised when a tile exceeds it by more than kRescaleThreshold
+// (log2 units), which removes the accumulator rescale from almost every tile.
+//
+// Workgroups that read the same (sequence, kv head) run on the same XCD (ids congruent
+// mod 8 share an XCD under round-robin dispatch), so K/V re-reads hit that XCD's L2.
 //
 // Mask: causal, aligned to the bottom-right corner (query i of n_q sees keys
 // j <= n_k - n_q + i), which is what chunked prefill needs (n_k = computed + n_q).
@@ -18,9 +25,9 @@
 
 namespace nv {
 
-constexpr int kBM = 128;  // query rows per workgroup
-constexpr int kBN = 64;   // keys per tile
-constexpr float kMasked = -1.0e30f;
+constexpr int kBN = 64;                     // keys per tile
+constexpr float kRunInit = -1.0e30f;        // finite initial running max (keeps exp2 NaN-free)
+constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 between rescales
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -33,7 +40,12 @@ struct PrefillParams {
     const int32_t* cu_q;
     const int32_t* cu_k;
     const int32_t* block_tables;
-    int B, max_blocks, H_q, H_kv, block_size, n_qtiles;
+    int B, max_blocks, H_q, H_kv, block_size;
+    int hpw;          // query heads per workgroup (divides G and 4)
+    int rows_per_wg;  // 32 * (4 / hpw)
+    int n_qtiles;     // ceil(max_seqlen_q / rows_per_wg)
+    int wg_per_pair;  // n_qtiles * (G / hpw): workgroups of one (sequence, kv head)
+    int n_pairs;      // B * H_kv
     int64_t num_blocks;
     int64_t q_stride_vec, o_stride;
     float scale_log2;
@@ -59,20 +71,30 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    const int b = blockIdx.z;
-    const int hq = blockIdx.y;
-    const int qt = p.n_qtiles - 1 - blockIdx.x;  // heaviest (latest) tiles first
+    // ---- workgroup -> (sequence, kv head, head group, query tile), XCD-aware ----
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int pair = (slot / p.wg_per_pair) * 8 + xcd;
+    if (pair >= p.n_pairs) return;
+    const int widx = slot % p.wg_per_pair;
+    const int groups = p.wg_per_pair / p.n_qtiles;      // head groups per kv head (G / hpw)
+    const int hg = widx % groups;
+    const int qt = p.n_qtiles - 1 - widx / groups;      // heaviest (latest) tiles first
+    const int b = pair / p.H_kv;
+    const int hkv = pair - b * p.H_kv;
+    const int G = p.H_q / p.H_kv;
+    const int hq = hkv * G + hg * p.hpw + wave % p.hpw;
+
     const int q_begin = p.cu_q[b];
     const int n_q = p.cu_q[b + 1] - q_begin;
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
-    if (n_q <= 0 || qt * kBM >= n_q) return;
+    const int q0 = qt * p.rows_per_wg;                  // first query row of the workgroup
+    if (n_q <= 0 || q0 >= n_q) return;
     if (p.skip_single && n_q == 1) return;
-    const int hkv = hq / (p.H_q / p.H_kv);
-    const int shift = n_k - n_q;            // query i sees keys <= i + shift
-    const int q0 = qt * kBM;                // first query row of the workgroup
-    const int rw0 = q0 + wave * 32;         // first query row of the wave
+    const int shift = n_k - n_q;                        // query i sees keys <= i + shift
+    const int rw0 = q0 + (wave / p.hpw) * 32;           // first query row of the wave
     const bool wave_live = rw0 < n_q;
-    const int last_row = min(q0 + kBM, n_q) - 1;
+    const int last_row = min(q0 + p.rows_per_wg, n_q) - 1;
     const int max_key = min(last_row + shift, n_k - 1);  // last key any row here can see
     const int nt = max_key >= 0 ? max_key / kBN + 1 : 0;
 
@@ -90,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
-    float m_run = kMasked;  // running max (log2 domain), shared by lanes l and l^32
-    float l_run = 0.f;      // this lane's share of the running denominator
+    float m_run = kRunInit;  // reference max of the exponentials (log2 domain), lanes l and l^32 agree
+    float l_run = 0.f;       // this lane's share of the running denominator
 
     // ---- staging: K/V tiles go global -> LDS by LDS-DMA (no registers), double-buffered.
     // One DMA wave-instruction fills 1 KiB of LDS linearly (lane l -> byte 16 l), i.e. two
@@ -103,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     // issue right after the barrier never waits on the table.
     const int tiles_per_block = p.block_size / kBN;
     auto table_entry = [&](int t) { return bt[t / tiles_per_block]; };
-    auto stage = [&](int t, int buf, int phys_entry) {
+    auto stage = [&](int t, int phys_entry) {
+        const int buf = t & 1;
         const int key0 = t * kBN;
         // block_size is a multiple of 64 here, so a tile sits inside one cache block
         const int off = (t % tiles_per_block) * kBN;
@@ -129,8 +152,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     };
 
     int phys_next = 0;  // table entry of tile t+1 while tile t is computed
-    if (nt > 0) stage(0, 0, table_entry(0));
+    if (nt > 0) stage(0, table_entry(0));
     if (nt > 1) phys_next = table_entry(1);
+
+    const int i16 = lane & 15;
+    const int g16 = (lane >> 4) & 1;
+    const int qpos = rw0 + r + shift;               // last visible key of this lane's query row
+    const int wave_last_key = min(rw0 + 31, n_q - 1) + shift;  // last key any row of the wave sees
 
     for (int t = 0; t < nt; ++t) {
         // tile t has landed for every wave, and every wave is done reading the other buffer
@@ -138,110 +166,89 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         __syncthreads();
         const int phys_use = phys_next;
         if (t + 2 < nt) phys_next = table_entry(t + 2);
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1, phys_use);
+        if (t + 1 < nt) stage(t + 1, phys_use);
         const unsigned char* ldsK = lds + (t & 1) * 32768;
         const unsigned char* ldsV = ldsK + 16384;
         const int kt = t * kBN;
         // wave-uniform: does this wave have any row that sees a key of this tile?
-        const bool active = wave_live && kt <= min(rw0 + 31, n_q - 1) + shift;
-        if (active) {
-            // ---------------- S^T = K . Q^T : 2 key blocks of 32 ----------------
-            f32x16 sacc[2];
+        if (!(wave_live && kt <= wave_last_key)) continue;
+
+        // ---------------- S^T = K . Q^T : 2 key blocks of 32 ----------------
+        f32x16 sacc[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
-                const int row = kb * 32 + r;
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
+            const int row = kb * 32 + r;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const bf16x8 a = __builtin_bit_cast(
-                        bf16x8, *reinterpret_cast<const uint4*>(ldsK + tile_off(row, 2 * s + h)));
-                    sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+            for (int s = 0; s < 8; ++s) {
+                const bf16x8 a = __builtin_bit_cast(
+                    bf16x8, *reinterpret_cast<const uint4*>(ldsK + tile_off(row, 2 * s + h)));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---------------- online softmax over the 64 keys (raw scores, scale folded in) ----
+        // register i of block kb is key kt + kb*32 + (i&3) + 8*(i>>2) + 4h; query row rw0 + r
+        if (kt + kBN - 1 > rw0 + shift) {  // wave-uniform: the tile touches the diagonal
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int key = kt + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sacc[kb][i] = key <= qpos ? sacc[kb][i] : -INFINITY;
                 }
-            }
-            // ---------------- online softmax over the 64 keys ----------------
-            // register i of block kb is key kt + kb*32 + (i&3) + 8*(i>>2) + 4h; query row rw0 + r
-            const int qpos = rw0 + r + shift;  // last visible key of this lane's query row
-            const bool need_mask = kt + kBN - 1 > rw0 + shift;  // wave-uniform
-            float tmax = kMasked;
-            if (need_mask) {
+        }
+        float tmax = sacc[0][0];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[0][i]);
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = kt + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        const float s = key <= qpos ? sacc[kb][i] * p.scale_log2 : kMasked;
-                        sacc[kb][i] = s;
-                        tmax = fmaxf(tmax, s);
-                    }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float s = sacc[kb][i] * p.scale_log2;
-                        sacc[kb][i] = s;
-                        tmax = fmaxf(tmax, s);
-                    }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[1][i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale_log2;
+        if (!__all(tmax <= m_run + kRescaleThreshold)) {  // rare after the first tiles
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            float psum = 0.f;
-            if (need_mask) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float s = sacc[kb][i];
-                        const float e = s > 0.5f * kMasked ? __builtin_amdgcn_exp2f(s - m_new) : 0.f;
-                        sacc[kb][i] = e;
-                        psum += e;
-                    }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float e = __builtin_amdgcn_exp2f(sacc[kb][i] - m_new);
-                        sacc[kb][i] = e;
-                        psum += e;
-                    }
-            }
-            l_run = l_run * alpha + psum;
+            l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], p.scale_log2, -m_run));
+                sacc[kb][i] = e;
+                psum += e;
+            }
+        l_run += psum;
 
-            // ---------------- O^T += V^T . P^T : 4 k-steps of 16 keys ----------------
-            const int i16 = lane & 15;
-            const int g16 = (lane >> 4) & 1;
+        // ---------------- O^T += V^T . P^T : 4 k-steps of 16 keys ----------------
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int kb = s >> 1;
-                const int s2 = s & 1;
-                bf16x8 pb;
+        for (int s = 0; s < 4; ++s) {
+            const int kb = s >> 1;
+            const int s2 = s & 1;
+            bf16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)sacc[kb][8 * s2 + j];
-                // keys of element j: kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)
-                const int row1 = kb * 32 + 16 * s2 + 4 * h + (i16 >> 2);
-                const int row2 = row1 + 8;
+            for (int j = 0; j < 8; ++j) pb[j] = (__bf16)sacc[kb][8 * s2 + j];
+            // keys of element j: kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)
+            const int row1 = kb * 32 + 16 * s2 + 4 * h + (i16 >> 2);
+            const int row2 = row1 + 8;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    const int ch = d * 4 + 2 * g16 + ((i16 & 3) >> 1);
-                    const int sub = 8 * (i16 & 1);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (lds_s16x4*)(ldsV + tile_off(row1, ch) + sub));
-                    const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (lds_s16x4*)(ldsV + tile_off(row2, ch) + sub));
-                    s16x8 va;
-                    va[0] = v1[0]; va[1] = v1[1]; va[2] = v1[2]; va[3] = v1[3];
-                    va[4] = v2[0]; va[5] = v2[1]; va[6] = v2[2]; va[7] = v2[3];
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va),
-                                                                      pb, oacc[d], 0, 0, 0);
-                }
+            for (int d = 0; d < 4; ++d) {
+                const int ch = d * 4 + 2 * g16 + ((i16 & 3) >> 1);
+                const int sub = 8 * (i16 & 1);
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4*)(ldsV + tile_off(row1, ch) + sub));
+                const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (lds_s16x4*)(ldsV + tile_off(row2, ch) + sub));
+                s16x8 va;
+                va[0] = v1[0]; va[1] = v1[1]; va[2] = v1[2]; va[3] = v1[3];
+                va[4] = v2[0]; va[5] = v2[1]; va[6] = v2[2]; va[7] = v2[3];
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), pb,
+                                                                  oacc[d], 0, 0, 0);
             }
         }
     }
@@ -262,6 +269,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
             *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * h) = w;
         }
 }
+
+static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 
 }  // namespace nv
 
@@ -291,8 +300,6 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
                NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: pointers must be 16-byte aligned");
     NV_REQUIRE((int64_t)max_blocks * block_size >= max_seqlen_k, NV_ERR_INVALID_ARG,
                "nv_attn_prefill_varlen: block table too narrow for max_seqlen_k");
-    NV_REQUIRE(H_q <= 65535 && B <= 65535, NV_ERR_UNSUPPORTED,
-               "nv_attn_prefill_varlen: H_q and B must be <= 65535");
 
     PrefillParams p;
     p.q = (const uint4*)q;
@@ -307,13 +314,19 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.H_q = H_q;
     p.H_kv = H_kv;
     p.block_size = block_size;
-    p.n_qtiles = (max_seqlen_q + kBM - 1) / kBM;
+    const int G = H_q / H_kv;
+    p.hpw = gcd_int(G, 4);
+    p.rows_per_wg = 32 * (4 / p.hpw);
+    p.n_qtiles = (max_seqlen_q + p.rows_per_wg - 1) / p.rows_per_wg;
+    p.wg_per_pair = p.n_qtiles * (G / p.hpw);
+    p.n_pairs = B * H_kv;
     p.num_blocks = num_blocks;
     p.q_stride_vec = q_stride_t / 8;
     p.o_stride = o_stride_t;
     p.scale_log2 = scale * 1.4426950408889634f;
     p.skip_single = skip_single_query;
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3(p.n_qtiles, H_q, B), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    const int64_t grid = (int64_t)((p.n_pairs + 7) / 8) * 8 * p.wg_per_pair;
+    NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("nv_attn_prefill_varlen");
 }
