@@ -45,8 +45,9 @@ class LLMEngine:
     def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
                  max_num_batched_tokens: int = 4000, long_prefill_token_threshold: int = 512,
                  gpu_memory_utilization: float = 0.9, device="cuda", eos: int | None = None,
-                 max_num_seqs: int | None = None, tokenizer=None):
-        self.runner = ModelRunner(model, cfg, block_size, num_kvcache_blocks, gpu_memory_utilization, device)
+                 max_num_seqs: int | None = None, tokenizer=None, use_graphs: bool = False):
+        self.runner = ModelRunner(model, cfg, block_size, num_kvcache_blocks, gpu_memory_utilization, device,
+                                  use_graphs=use_graphs)
         self.scheduler = Scheduler(self.runner.num_kvcache_blocks, block_size, max_num_batched_tokens,
                                    long_prefill_token_threshold, eos if eos is not None else cfg.eos_token_id,
                                    max_num_seqs)

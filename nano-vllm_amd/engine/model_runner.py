@@ -55,14 +55,69 @@ def prepare_inputs(seqs: list[Sequence], block_size: int) -> dict:
                 num_decode_seqs=n_decode)
 
 
+class _DecodeGraph:
+    """A captured decode step for one (padded batch, padded table width) shape with its static buffers."""
+
+    def __init__(self, runner: "ModelRunner", batch: int, width: int):
+        dev = runner.device
+        self.batch, self.width = batch, width
+        self.input_ids = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.positions = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.slot_mapping = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        self.cu_seqlens_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
+        self.cu_seqlens_k = torch.zeros(batch + 1, dtype=torch.int32, device=dev)
+        self.block_tables = torch.full((batch, width), -1, dtype=torch.int32, device=dev)
+        self.ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self.slot_mapping,
+                                cu_seqlens_q=self.cu_seqlens_q, cu_seqlens_k=self.cu_seqlens_k, max_seqlen_q=1,
+                                max_seqlen_k=width * runner.block_size, block_tables=self.block_tables,
+                                block_size=runner.block_size, num_decode_seqs=batch)
+        set_context(self.ctx)
+        # warm-up on a side stream (library initialisation must not happen inside the capture)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            runner.model(self.input_ids, self.positions)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = runner.model(self.input_ids, self.positions)
+
+    def replay(self, m: dict, to_device) -> torch.Tensor:
+        n = len(m["input_ids"])
+        pad = self.batch - n
+        bt = m["block_tables"]
+        if pad or bt.shape[1] < self.width:
+            full = np.full((self.batch, self.width), -1, dtype=np.int32)
+            full[:n, :bt.shape[1]] = bt
+            bt = full
+        cu_k = m["cu_seqlens_k"]
+        if pad:                                   # padded rows: no keys, slot -1 (skipped), token 0
+            cu_k = np.concatenate([cu_k, np.full(pad, cu_k[-1], dtype=np.int32)])
+        self.input_ids[:n].copy_(to_device(m["input_ids"]), non_blocking=True)
+        self.positions[:n].copy_(to_device(m["positions"]), non_blocking=True)
+        self.slot_mapping[:n].copy_(to_device(m["slot_mapping"]), non_blocking=True)
+        if pad:
+            self.slot_mapping[n:].fill_(-1)
+        self.cu_seqlens_k.copy_(to_device(cu_k), non_blocking=True)
+        self.block_tables.copy_(to_device(bt), non_blocking=True)
+        self.graph.replay()
+        return self.logits[:n]
+
+
 class ModelRunner:
     def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
                  gpu_memory_utilization: float = 0.9, device: str | torch.device = "cuda",
-                 dtype: torch.dtype = torch.bfloat16):
+                 dtype: torch.dtype = torch.bfloat16, use_graphs: bool = False):
         self.model, self.cfg, self.block_size = model, cfg, block_size
         self.device, self.dtype = torch.device(device), dtype
         self.kv_cache: torch.Tensor | None = None
         self.num_kvcache_blocks = self.init_kv_cache(num_kvcache_blocks, gpu_memory_utilization)
+        # Decode steps (one token per sequence) can be replayed from captured HIP graphs: the
+        # kernels of a step are launch-latency-bound on small models.  No counterpart in the
+        # reference (its README lists CUDA graphs as future work).
+        self.use_graphs = use_graphs and self.device.type == "cuda"
+        self._graphs: dict[tuple[int, int], _DecodeGraph] = {}
 
     # ---- KV cache -------------------------------------------------------------------------
     def block_bytes(self) -> int:
@@ -110,9 +165,20 @@ class ModelRunner:
     def run(self, seqs: list[Sequence]) -> list[int | None]:
         """Forward the scheduled tokens; returns one sampled token per sequence, or None while a
         sequence's prompt is still being chunked (model_runner.py:214-240)."""
-        input_ids, positions, m = self.set_step_context(seqs)
-        last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)
-        logits = self.model(input_ids, positions, logits_rows=last_rows)          # [B, vocab]
+        if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
+            m = prepare_inputs(seqs, self.block_size)
+            batch = -(-len(seqs) // 16) * 16
+            width = 1 << max(0, int(m["block_tables"].shape[1] - 1).bit_length())     # next power of two
+            key = (batch, width)
+            if key not in self._graphs:
+                self._graphs[key] = _DecodeGraph(self, batch, width)
+            g = self._graphs[key]
+            set_context(g.ctx)
+            logits = g.replay(m, self._to_device)
+        else:
+            input_ids, positions, m = self.set_step_context(seqs)
+            last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)
+            logits = self.model(input_ids, positions, logits_rows=last_rows)      # [B, vocab]
         temps = [s.sampling_params.temperature for s in seqs]
         tokens = sample(logits, temps).tolist()
         out = []

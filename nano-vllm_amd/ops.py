@@ -14,6 +14,7 @@ from . import _lib
 
 _BF16 = torch.bfloat16
 _workspaces: dict[int, torch.Tensor] = {}
+_retired: list[torch.Tensor] = []   # outgrown workspaces stay alive: captured graphs may point at them
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -44,7 +45,9 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     idx = device.index if device.index is not None else torch.cuda.current_device()
     ws = _workspaces.get(idx)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         _workspaces[idx] = ws
     return ws
 

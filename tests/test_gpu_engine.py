@@ -25,29 +25,78 @@ def build(cfg, layers, fused, seed=0):
     return model.to(torch.bfloat16).to(DEV)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_greedy_tokens_identical_over_128_steps(fused):
+def _drive(engine, prompts, max_tokens, forced=None):
+    """Run the engine step by step with argmax decoding.  Returns per sequence the list of
+    (chosen token, logits row) for every sampled position.  With `forced` (token lists per
+    sequence) the engine is teacher-forced: the given token is appended instead of its own argmax."""
+    seqs = [engine.add_request(p, SamplingParams(0.0, max_tokens)) for p in prompts]
+    index = {s.id: i for i, s in enumerate(seqs)}
+    trace = [[] for _ in seqs]
+    runner, sched = engine.runner, engine.scheduler
+    while not sched.is_finished():
+        batch, _ = sched.schedule()
+        ids, pos, meta = runner.set_step_context(batch)
+        last = torch.from_numpy(meta["cu_seqlens_q"][1:].astype("int64") - 1).to(DEV)
+        with torch.inference_mode():
+            logits = runner.model(ids, pos, logits_rows=last).float()
+        picks = logits.argmax(dim=-1).tolist()
+        out = []
+        for row, (s, tok) in enumerate(zip(batch, picks)):
+            if s.num_computed_tokens + s.num_scheduled_tokens < len(s.prompt_tokens):
+                out.append(None)
+                continue
+            i = index[s.id]
+            if forced is not None:
+                tok = forced[i][len(trace[i])]
+            trace[i].append((tok, logits[row].cpu()))
+            out.append(tok)
+        sched.update_from_output(batch, out)
+    return trace
+
+
+@pytest.mark.parametrize("fused,graphs", [(True, False), (False, False), (True, True)])
+def test_greedy_tokens_over_128_steps(fused, graphs):
     """Qwen3-0.6B-shaped attention (16 q / 8 kv heads x 128, q/k-norm, rope theta 1e6, block 256),
     fewer / narrower layers and a 4k vocabulary to keep the oracle run short; 4 prompts of lengths
-    16/13/512/502, argmax decoding for 128 steps through chunked prefill and batched decode."""
+    16/13/512/502, argmax decoding for 128 steps through chunked prefill and batched decode.
+
+    The HIP engine runs freely.  The oracle-module engine is then teacher-forced with the HIP
+    engine's tokens, which gives the reference logits for exactly the same contexts at every step.
+    Greedy tokens must be identical wherever the reference's top-2 margin is larger than the
+    numerical tolerance of the path; inside that margin (a numerical tie of random-init logits)
+    the HIP token must be one of the tied candidates."""
     cfg = ModelConfig(vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
                       num_attention_heads=16, num_key_value_heads=8, head_dim=128, max_position_embeddings=2048)
     g = torch.Generator().manual_seed(0)
     prompts = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in (16, 13, 512, 502)]
-    sp = SamplingParams(0.0, 128)
     hip_model = build(cfg, None, fused)
     ref_model = build(cfg, ref_modules, False)
     ref_model.load_state_dict(hip_model.state_dict())
-    hip = LLMEngine(hip_model, cfg, block_size=256, num_kvcache_blocks=16, max_num_batched_tokens=600,
-                    long_prefill_token_threshold=512, device=DEV, eos=-1)
-    ref = LLMEngine(ref_model, cfg, block_size=256, num_kvcache_blocks=16, max_num_batched_tokens=600,
-                    long_prefill_token_threshold=512, device=DEV, eos=-1)
-    out_hip, m = hip.generate(prompts, sp)
-    out_ref, _ = ref.generate(prompts, sp)
-    for a, b in zip(out_hip, out_ref):
-        assert len(a["token_ids"]) == 128
-        assert a["token_ids"] == b["token_ids"]
-    assert m.summary()["generated_tokens"] == 4 * 128
+    kw = dict(block_size=256, num_kvcache_blocks=16, max_num_batched_tokens=600, long_prefill_token_threshold=512,
+              device=DEV, eos=-1)
+    hip = LLMEngine(hip_model, cfg, use_graphs=graphs, **kw)
+    ref = LLMEngine(ref_model, cfg, **kw)
+    if graphs:      # the public generate() path exercises graph replay; compare its tokens with the eager HIP run
+        outs, m = hip.generate(prompts, SamplingParams(0.0, 128))
+        eager = LLMEngine(hip_model, cfg, **kw)
+        outs_eager, _ = eager.generate(prompts, SamplingParams(0.0, 128))
+        assert [o["token_ids"] for o in outs] == [o["token_ids"] for o in outs_eager]
+        assert m.summary()["generated_tokens"] == 4 * 128 and len(hip.runner._graphs) >= 1
+        return
+    hip_trace = _drive(hip, prompts, 128)
+    hip_tokens = [[t for t, _ in tr] for tr in hip_trace]
+    ref_trace = _drive(ref, prompts, 128, forced=hip_tokens)
+    assert all(len(t) == 128 for t in hip_tokens)
+    ties = 0
+    for tr_h, tr_r in zip(hip_trace, ref_trace):
+        for (tok, lg_h), (_, lg_r) in zip(tr_h, tr_r):
+            scale = max(1.0, lg_r.abs().max().item())
+            assert (lg_h - lg_r).abs().max().item() <= 2e-2 * scale           # logits agree at every step
+            top2 = lg_r.topk(2).values
+            if tok != int(lg_r.argmax()):
+                ties += 1
+                assert (top2[0] - lg_r[tok]).item() <= 2e-2 * scale, "token differs outside a numerical tie"
+    assert ties <= 8, f"{ties} of 512 greedy tokens fell on numerical ties"
     assert hip.scheduler.block_manager.num_free_blocks == 16
 
 
