@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--attn-only", action="store_true", help="step = decode attention launches only")
     ap.add_argument("--tp-layers", type=int, default=8, help="layers in the head-sharded sub-benchmark")
     ap.add_argument("--no-tp", action="store_true", help="skip the head-sharded sub-benchmark")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end generation run (N=1 only)")
     return ap.parse_args()
 
 
@@ -357,7 +358,17 @@ def main():
             out["head_sharded"] = tp
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(w, cpu_kv[0], cpu_kv[1], args.cpu_seconds)
+        if world == 1 and not args.no_e2e:
+            # BASELINE config 2 end to end: 256 prompts x 512 tokens in, 256 out, argmax, random-init
+            # Qwen3-0.6B-shaped weights; GEMMs are torch/hipBLASLt, the attention path is this library.
+            from tools.e2e_bench import run as e2e_run
+            del w
+            torch.cuda.empty_cache()
+            e = e2e_run(device=str(dev))
+            out["output_tok_per_s"] = round(e["output_tok_per_s"], 1)
+            out["e2e"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()}
         print(json.dumps(out), flush=True)
+        out = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -104,10 +104,32 @@ class Qwen3Attention(nn.Module):
                                      cfg.max_position_embeddings)
         self._fused = L.fused_qknorm_rope_store if fused else None
 
+    def fuse_weights(self) -> None:
+        """Make q/k/v_proj.weight views of ONE [q+2kv, hidden] tensor so the three projections run
+        as a single GEMM; parameter names and values are unchanged (call after loading weights)."""
+        if self.q_proj.bias is not None:
+            return
+        w = torch.cat([self.q_proj.weight.data, self.k_proj.weight.data, self.v_proj.weight.data], dim=0)
+        self.q_proj.weight.data = w[:self.q_size]
+        self.k_proj.weight.data = w[self.q_size:self.q_size + self.kv_size]
+        self.v_proj.weight.data = w[self.q_size + self.kv_size:]
+        self._qkv_weight = w
+
+    def _project(self, x: torch.Tensor):
+        w = getattr(self, "_qkv_weight", None)
+        if w is not None and w.device == x.device and w.dtype == x.dtype:
+            qkv = F.linear(x, w)                       # [T, q+2kv]; the slices below keep its token stride
+            q = qkv[:, :self.q_size]
+            k = qkv[:, self.q_size:self.q_size + self.kv_size]
+            v = qkv[:, self.q_size + self.kv_size:]
+        else:
+            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        T = x.shape[0]
+        return (q.unflatten(1, (self.num_heads, self.head_dim)), k.unflatten(1, (self.num_kv_heads, self.head_dim)),
+                v.unflatten(1, (self.num_kv_heads, self.head_dim)))
+
     def forward(self, x: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
-        q = self.q_proj(x).view(-1, self.num_heads, self.head_dim)
-        k = self.k_proj(x).view(-1, self.num_kv_heads, self.head_dim)
-        v = self.v_proj(x).view(-1, self.num_kv_heads, self.head_dim)
+        q, k, v = self._project(x)
         if self._fused is not None:
             q = self._fused(positions, q, k, v, self.q_norm.weight if self.qk_norm else None,
                             self.k_norm.weight if self.qk_norm else None, self.rope, self.eps, self.attention)
@@ -127,7 +149,20 @@ class Qwen3MLP(nn.Module):
         self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
 
+    def fuse_weights(self) -> None:
+        """gate_proj / up_proj weights become views of one [2I, hidden] tensor: one GEMM for both."""
+        w = torch.cat([self.gate_proj.weight.data, self.up_proj.weight.data], dim=0)
+        n = self.gate_proj.weight.shape[0]
+        self.gate_proj.weight.data = w[:n]
+        self.up_proj.weight.data = w[n:]
+        self._gate_up_weight = w
+
     def forward(self, x):
+        w = getattr(self, "_gate_up_weight", None)
+        if w is not None and w.device == x.device and w.dtype == x.dtype:
+            gu = F.linear(x, w)
+            n = w.shape[0] // 2
+            return self.down_proj(F.silu(gu[:, :n]) * gu[:, n:])
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
@@ -176,6 +211,15 @@ class Qwen3ForCausalLM(nn.Module):
         self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
         if cfg.tie_word_embeddings:
             self.lm_head.weight = self.model.embed_tokens.weight
+
+    def fuse_weights(self) -> "Qwen3ForCausalLM":
+        """Fuse the q/k/v and gate/up projection weights of every layer (after weights are loaded and
+        the model sits on its final device / dtype).  Outputs are unchanged: the same rows of the same
+        matrices are multiplied, in one GEMM instead of three / two."""
+        for layer in self.model.layers:
+            layer.self_attn.fuse_weights()
+            layer.mlp.fuse_weights()
+        return self
 
     def forward(self, input_ids, positions, logits_rows=None):
         """logits_rows: optional index tensor; when given only those token rows go through lm_head."""

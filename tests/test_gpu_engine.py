@@ -76,6 +76,8 @@ def test_greedy_tokens_over_128_steps(fused, graphs):
               device=DEV, eos=-1)
     hip = LLMEngine(hip_model, cfg, use_graphs=graphs, **kw)
     ref = LLMEngine(ref_model, cfg, **kw)
+    if graphs:
+        hip_model.fuse_weights()                  # fused q/k/v and gate/up GEMMs: same math, fewer launches
     if graphs:      # the public generate() path exercises graph replay; compare its tokens with the eager HIP run
         outs, m = hip.generate(prompts, SamplingParams(0.0, 128))
         eager = LLMEngine(hip_model, cfg, **kw)

@@ -18,7 +18,7 @@ from nanovllm_amd.model.qwen3 import ModelConfig, Qwen3ForCausalLM  # noqa: E402
 
 
 def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device="cuda:0", seed=0,
-        max_num_batched_tokens=4000, fused=True, graphs=True):
+        max_num_batched_tokens=4000, fused=True, graphs=True, fuse_gemms=True):
     cfg = getattr(ModelConfig, model_name)()
     torch.manual_seed(seed)
     with torch.device(device):
@@ -29,6 +29,8 @@ def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device=
         else:
             torch.nn.init.normal_(p, 0.0, 0.02)
     model = model.to(torch.bfloat16)
+    if fuse_gemms:
+        model.fuse_weights()
     blocks = batch * (-(-(prompt_len + out_len) // 256)) + 8
     eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=blocks, max_num_batched_tokens=max_num_batched_tokens,
                     device=device, eos=-1, use_graphs=graphs)
@@ -40,7 +42,7 @@ def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device=
     torch.cuda.synchronize()
     outs, metrics = eng.generate(prompts, SamplingParams(0.0, out_len))
     s = metrics.summary()
-    s.update(model=model_name, batch=batch, prompt_len=prompt_len, out_len=out_len, fused=fused, graphs=graphs)
+    s.update(model=model_name, batch=batch, prompt_len=prompt_len, out_len=out_len, fused=fused, graphs=graphs, fuse_gemms=fuse_gemms)
     return s
 
 
@@ -52,5 +54,6 @@ if __name__ == "__main__":
     ap.add_argument("--out-len", type=int, default=256)
     ap.add_argument("--unfused", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-fuse-gemms", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.model, a.batch, a.prompt_len, a.out_len, fused=not a.unfused, graphs=not a.no_graphs)))
+    print(json.dumps(run(a.model, a.batch, a.prompt_len, a.out_len, fused=not a.unfused, graphs=not a.no_graphs, fuse_gemms=not a.no_fuse_gemms)))
