@@ -268,6 +268,261 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     }
 }
 
+// Variant for G >= 4 query heads per kv head.  The per-(key, head) lane reductions of the
+// kernel above cost 5 VALU ops per score and make it instruction-bound once G reaches 4;
+// here the scores of a 16-key tile come from four v_mfma_f32_16x16x32_bf16
+// (S^T[key][q] = K . Q^T, K fragments loaded from global memory directly in operand shape,
+// 64 contiguous bytes per key row and instruction, Q fragments resident, columns >= G zero).
+// Lane (c = lane & 15, r = lane >> 4) then holds S^T[4r + i][q = c], i = 0..3: every score
+// exists once per wave, so the exponentials are not replicated.  The probabilities go
+// through a 512-byte per-wave LDS exchange into the V layout of the kernel above (lane =
+// (key 4i + r of load i, 16-byte piece c)), where PV stays packed fp32 FMAs.
+// The running maximum is uniform per query head across the wave and only raised when a
+// score exceeds it by more than 2^kDecRaise (then the accumulators are rescaled), so the
+// common tile has no cross-lane maximum at all.
+constexpr float kDecRaise = 8.0f;
+
+template <int G, bool ALIGNED, int kDepth>
+__global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
+    static_assert(G == 4 || G == 8, "query heads per kv head");
+    __shared__ __attribute__((aligned(16))) float xch_all[kDecWaves][16 * G + 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r4 = lane >> 4;  // S^T: key group; V layout: key of a 4-key load
+    const int c = lane & 15;   // S^T: query head; V layout: 16-byte piece of the head row
+    float* xp = xch_all[wave];       // [16 keys][G] probabilities of the current tile
+    float* xa = xch_all[wave] + 16 * G;  // [16] per-head scalars (alpha, then m, l)
+
+    const int item = blockIdx.x * kDecWaves + wave;
+    const int h = item % p.H_kv;
+    const int rest = item / p.H_kv;
+    const int split = rest % p.nsplit;
+    const int b = rest / p.nsplit;
+    if (b >= p.B) return;
+
+    const int n_k = p.cu_k[b + 1] - p.cu_k[b];
+    int tq = b;
+    if (p.cu_q) {
+        if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // not a decode row
+        tq = p.cu_q[b];
+    }
+    const int k0 = split * p.chunk;
+    if (k0 >= n_k && !(split == 0)) return;
+    const int k1 = min(k0 + p.chunk, n_k);
+    const int H_q = p.H_kv * G;
+
+    // B operand: lane (c, r4) holds Q[head c][dims 32 s + 8 r4 .. +7] for k-step s
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < G) v = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * G + c) * 16 + 4 * s + r4];
+        qf[s] = __builtin_bit_cast(bf16x8, v);
+    }
+
+    float m_run = kNegBig, l_part = 0.f;
+    float acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+
+    const int n_keys = k1 - k0;
+    const int nt = n_keys > 0 ? (n_keys + 15) >> 4 : 0;
+    const int32_t* bt = p.block_tables + (int64_t)b * p.max_blocks;
+    const int row_vec = p.H_kv * 16;
+
+    uint4 kbuf[kDepth + 1][4], vbuf[kDepth + 1][4];
+    int cur_blk = k0 / p.block_size;
+    int cur_off = k0 - cur_blk * p.block_size;
+    int cur_key = k0;
+    auto resolve = [&](int key) -> int64_t {  // first uint4 of this head's row of a logical key
+        key = key < k1 ? key : k1 - 1;
+        const int blk = key / p.block_size;
+        const int off = key - blk * p.block_size;
+        int64_t phys = bt[blk];
+        phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
+        return ((phys * p.block_size + off) * p.H_kv + h) * 16;
+    };
+    auto tile_load = [&](uint4 (&kd)[4], uint4 (&vd)[4]) {
+        if (ALIGNED) {
+            int64_t phys = __builtin_amdgcn_readfirstlane(bt[cur_blk]);
+            phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
+            const int64_t base = ((phys * p.block_size + cur_off) * p.H_kv + h) * 16;
+            const int kr = (cur_key + c) < k1 ? c : 0;  // A operand row = key c of the tile
+            const int64_t kvec = base + kr * row_vec + r4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kd[s] = kv_load(p.k_cache + kvec + 4 * s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = 4 * i + r4;
+                const int jj = (cur_key + j) < k1 ? j : 0;
+                vd[i] = kv_load(p.v_cache + base + jj * row_vec + c);
+            }
+        } else {
+            const int64_t kvec = resolve(cur_key + c) + r4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kd[s] = kv_load(p.k_cache + kvec + 4 * s);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vd[i] = kv_load(p.v_cache + resolve(cur_key + 4 * i + r4) + c);
+        }
+        cur_key += 16;
+        cur_off += 16;
+        if (cur_off >= p.block_size) {
+            cur_off -= p.block_size;
+            ++cur_blk;
+        }
+    };
+
+    // G consecutive floats of the exchange area (the widest LDS reads that fit)
+    auto read_heads = [&](const float* src, float (&dst)[G]) {
+        if constexpr (G >= 4) {
+#pragma unroll
+            for (int g4 = 0; g4 < G / 4; ++g4) {
+                const float4 a = *reinterpret_cast<const float4*>(src + 4 * g4);
+                dst[4 * g4] = a.x;
+                dst[4 * g4 + 1] = a.y;
+                dst[4 * g4 + 2] = a.z;
+                dst[4 * g4 + 3] = a.w;
+            }
+        } else if constexpr (G == 2) {
+            const float2 a = *reinterpret_cast<const float2*>(src);
+            dst[0] = a.x;
+            dst[1] = a.y;
+        } else {
+            dst[0] = src[0];
+        }
+    };
+
+    auto tile_compute = [&](int t, const uint4 (&kd)[4], const uint4 (&vd)[4]) {
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kd[s]), qf[s], sacc, 0, 0, 0);
+        float sc[4];
+        const int key_base = k0 + 16 * t + 4 * r4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sc[i] = (key_base + i) < k1 ? sacc[i] * p.scale_log2 : kNegBig;
+        const float lmax = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        if (__builtin_amdgcn_ballot_w64(lmax > m_run + kDecRaise) != 0) {
+            // raise the running maxima (uniform over the four key groups) and rescale
+            float tm = fmaxf(lmax, __shfl_xor(lmax, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float m_new = fmaxf(m_run, tm);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_part *= alpha;
+            if (r4 == 0) xa[c] = alpha;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float av[G];
+            read_heads(xa, av);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[g][j] *= av[g];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            sc[i] = __builtin_amdgcn_exp2f(sc[i] - m_run);  // masked keys: exp2(-1e30 - m) = 0
+            ps += sc[i];
+        }
+        l_part += ps;
+        if (c < G) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xp[(4 * r4 + i) * G + c] = sc[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float pg[G];
+            read_heads(xp + (4 * i + r4) * G, pg);
+            const uint32_t vu[4] = {vd[i].x, vd[i].y, vd[i].z, vd[i].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float lo = bf16_lo(vu[w]), hi = bf16_hi(vu[w]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    acc[g][2 * w] += pg[g] * lo;
+                    acc[g][2 * w + 1] += pg[g] * hi;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d)
+        if (d < nt) tile_load(kbuf[d], vbuf[d]);
+    for (int t = 0; t < nt; t += kDepth + 1) {
+#pragma unroll
+        for (int u = 0; u <= kDepth; ++u) {
+            if (t + u < nt) {
+                if (t + u + kDepth < nt) tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
+                tile_compute(t + u, kbuf[u], vbuf[u]);
+            }
+        }
+    }
+
+    // Denominators: sum the four key groups, then hand (m, l) per head to the V-layout lanes.
+    float l_tot = l_part + __shfl_xor(l_part, 16);
+    l_tot += __shfl_xor(l_tot, 32);
+    if (r4 == 0) xa[c] = l_tot;
+    if (r4 == 1) xp[c] = m_run;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float l[G], m[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        l[g] = xa[g];
+        m[g] = xp[g];
+    }
+    // All four key rows share one reference maximum: plain sums merge them.
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = acc[g][j];
+            a += __shfl_xor(a, 16);
+            a += __shfl_xor(a, 32);
+            acc[g][j] = a;
+        }
+
+    if (r4 != 0) return;
+    if (p.nsplit == 1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float inv = l[g] > 0.f ? 1.0f / l[g] : 0.f;
+            uint4 ov;
+            ov.x = pack_bf16(acc[g][0] * inv, acc[g][1] * inv);
+            ov.y = pack_bf16(acc[g][2] * inv, acc[g][3] * inv);
+            ov.z = pack_bf16(acc[g][4] * inv, acc[g][5] * inv);
+            ov.w = pack_bf16(acc[g][6] * inv, acc[g][7] * inv);
+            p.o[(int64_t)tq * p.o_stride_vec + (int64_t)(h * G + g) * 16 + c] = ov;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float* dst = p.part + (((int64_t)b * H_q + (h * G + g)) * p.nsplit + split) * kPartStride;
+            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
+            d4[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            d4[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+            if (c == 0) {
+                dst[kHeadDim] = m[g];
+                dst[kHeadDim + 1] = l[g];
+            }
+        }
+    }
+}
+
 // Combine the per-chunk partial states of one (sequence, query head): 32 threads, 4 dims each.
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int H_q) {
     const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -418,14 +673,38 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         if (aligned) NV_DEC_LAUNCH2(GG, true); \
         else NV_DEC_LAUNCH2(GG, false);      \
     } while (0)
+    // NV_DECODE_VALU=1 keeps G >= 4 on the all-VALU kernel: a tuning / comparison aid
+    const char* ve = getenv("NV_DECODE_VALU");
+    const bool use_mfma = G >= 4 && !(ve && atoi(ve) > 0);
+    // one tile of prefetch measured faster than none on every G >= 4 shape tried
+    const char* de = getenv("NV_DECODE_MFMA_DEPTH");  // tuning aid
+    const bool mfma_deep = de ? atoi(de) > 0 : true;
+#define NV_DEC_LAUNCH_M2(GG, AL)                                                                    \
+    do {                                                                                            \
+        if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 0>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
+    } while (0)
+#define NV_DEC_LAUNCH_M(GG)                      \
+    do {                                         \
+        if (aligned) NV_DEC_LAUNCH_M2(GG, true); \
+        else NV_DEC_LAUNCH_M2(GG, false);        \
+    } while (0)
     switch (G) {
         case 1: NV_DEC_LAUNCH(1); break;
         case 2: NV_DEC_LAUNCH(2); break;
-        case 4: NV_DEC_LAUNCH(4); break;
-        default: NV_DEC_LAUNCH(8); break;
+        case 4:
+            if (use_mfma) NV_DEC_LAUNCH_M(4);
+            else NV_DEC_LAUNCH(4);
+            break;
+        default:
+            if (use_mfma) NV_DEC_LAUNCH_M(8);
+            else NV_DEC_LAUNCH(8);
+            break;
     }
 #undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH
+#undef NV_DEC_LAUNCH_M2
+#undef NV_DEC_LAUNCH_M
     int rc = check_launch("nv_attn_decode_paged");
     if (rc != NV_OK) return rc;
     if (p.nsplit > 1) {

@@ -258,6 +258,31 @@ def test_decode_long_context_split(hip):
     _attn_check(_run_attention(ops, pd, "decode"), ref, "decode-long")
 
 
+@pytest.mark.parametrize("H_q,H_kv", [(16, 8), (32, 8), (64, 8)])
+@pytest.mark.parametrize("direction", ["rising", "falling"])
+def test_decode_monotone_scores(hip, H_q, H_kv, direction):
+    """Scores that grow (or shrink) steadily along the context: the running maximum is raised many
+    times (or exactly once), which exercises the accumulator rescale of the online softmax."""
+    _, ops = hip
+    n_ks = [300, 1000, 2049]
+    bs = 256
+    p = make_paged_problem(77, [1] * len(n_ks), n_ks, H_q, H_kv, bs, 16)
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn(128, generator=g)
+    p["q"] = (u[None, None, :] + 0.05 * torch.randn(len(n_ks), H_q, 128, generator=g)).bfloat16()
+    for b, n in enumerate(n_ks):
+        for j0 in range(0, n, bs):
+            blk = p["block_tables"][b, j0 // bs].item()
+            j = torch.arange(j0, min(j0 + bs, n), dtype=torch.float32)
+            ramp = (j / n) if direction == "rising" else (1.0 - j / n)
+            rows = 6.0 * ramp[:, None, None] * u[None, None, :] + 0.1 * torch.randn(len(j), H_kv, 128, generator=g)
+            p["k_cache"][blk, : len(j)] = rows.bfloat16()
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    _attn_check(_run_attention(ops, pd, "decode"), ref, f"decode-{direction}")
+
+
 def test_decode_zero_length_sequence_gives_zeros(hip):
     _, ops = hip
     p = make_paged_problem(9, [1, 1], [0, 40], 16, 8, 256, 3)

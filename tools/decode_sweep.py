@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ctx-hi", type=int, default=768)
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
@@ -46,6 +47,13 @@ def main():
     dlls = {name: _lib.load(path) for name, path in libs.items()}
     for rnd in range(args.rounds + 1):
         for name, dll in dlls.items():
+          for mode in args.modes.split(","):
+            os.environ.pop("NV_DECODE_VALU", None)
+            os.environ.pop("NV_DECODE_MFMA_DEPTH", None)
+            if mode == "valu":
+                os.environ["NV_DECODE_VALU"] = "1"
+            elif mode.startswith("mfma"):
+                os.environ["NV_DECODE_MFMA_DEPTH"] = mode[4:]
             for chunk in chunks:
                 os.environ.pop("NV_DECODE_CHUNK", None)
                 os.environ.pop("NV_DECODE_TARGET_WAVES", None)
@@ -65,15 +73,15 @@ def main():
                 b.record()
                 torch.cuda.synchronize()
                 if rnd > 0:
-                    results.setdefault((name, chunk), []).append(a.elapsed_time(b) / w.L)
+                    results.setdefault((name + ":" + mode, chunk), []).append(a.elapsed_time(b) / w.L)
     nbytes = w.attn_bytes_per_launch()
     print(f"workload: B={w.B} H_q={w.H_Q} H_kv={w.H_KV} ctx {min(w.ctx)}..{max(w.ctx)} bytes/launch={nbytes}")
     for (name, chunk), ts in sorted(results.items(), key=lambda kv: statistics.median(kv[1])):
         med, best = statistics.median(ts), min(ts)
         print(f"{name:>16s} chunk={chunk:4d}  median {med*1e3:8.2f} us  {nbytes/med/1e6:7.1f} GB/s   "
               f"best {best*1e3:8.2f} us {nbytes/best/1e6:7.1f} GB/s")
-    os.environ.pop("NV_DECODE_CHUNK", None)
-    os.environ.pop("NV_DECODE_TARGET_WAVES", None)
+    for k in ("NV_DECODE_CHUNK", "NV_DECODE_TARGET_WAVES", "NV_DECODE_VALU", "NV_DECODE_MFMA_DEPTH"):
+        os.environ.pop(k, None)
 
 
 if __name__ == "__main__":
