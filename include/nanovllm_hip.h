@@ -87,15 +87,24 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  *   cu_seqlens_q, cu_seqlens_k: [B+1] int32.  max_seqlen_q: host-side upper bound.
  *   skip_single_query != 0 leaves sequences with seqlen_q == 1 untouched (the caller
  *   runs nv_attn_decode_paged for them); 0 processes every sequence here.
+ *   total_q: number of query tokens (= cu_seqlens_q[B]); the block dimension y of the
+ *   merge launch is B, so B <= 65535 when the key range is split.
+ *   workspace: device scratch of at least nv_attn_prefill_workspace_bytes(...) bytes,
+ *   16-byte aligned, contents need no initialisation.  It is used only when the launch
+ *   would have too few workgroups for the chip (few long sequences): the key range is then
+ *   split over several workgroups and a second launch combines their states.
  * Rows with no visible key produce zeros.
  */
+NV_API int64_t nv_attn_prefill_workspace_bytes(int B, int total_q, int max_seqlen_q, int max_seqlen_k,
+                                        int H_q, int H_kv, int D);
 NV_API int nv_attn_prefill_varlen(const void* q, const void* k_cache, const void* v_cache, void* o,
                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                            const int32_t* block_tables, int B, int max_blocks,
                            int max_seqlen_q, int max_seqlen_k, int H_q, int H_kv, int D,
                            int64_t num_blocks, int block_size, float scale,
                            int64_t q_stride_t, int64_t o_stride_t,
-                           int skip_single_query, void* stream);
+                           int skip_single_query, int total_q,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * RMSNorm.  Replaces RMSNorm.forward without residual, nanovllm/layers/layernorm.py:79-100:

@@ -29,6 +29,8 @@ constexpr int kBN = 64;                     // keys per tile
 constexpr float kRunInit = -1.0e30f;        // finite initial running max (keeps exp2 NaN-free)
 constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 between rescales
 
+constexpr int kPartStride = kHeadDim + 4;    // fp32 per partial state: 128 acc + m + l + 2 pad
+
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -50,6 +52,11 @@ struct PrefillParams {
     int64_t q_stride_vec, o_stride;
     float scale_log2;
     int skip_single;
+    // key-range splitting (launches with too few workgroups for the chip)
+    float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states
+    int nsplit;           // 1: results are written directly
+    int tiles_per_split;  // 64-key tiles per split
+    int grid_base;        // workgroups per split (multiple of 8)
 };
 
 // LDS image of a [64 keys][128 dims] bf16 tile: 8-row x 32-column subtiles of 512 bytes,
@@ -72,8 +79,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const int h = lane >> 5;
 
     // ---- workgroup -> (sequence, kv head, head group, query tile), XCD-aware ----
-    const int xcd = blockIdx.x & 7;
-    const int slot = blockIdx.x >> 3;
+    const int split = blockIdx.x / p.grid_base;          // key range of this workgroup
+    const int bid = blockIdx.x - split * p.grid_base;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
     const int pair = (slot / p.wg_per_pair) * 8 + xcd;
     if (pair >= p.n_pairs) return;
     const int widx = slot % p.wg_per_pair;
@@ -96,7 +105,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const bool wave_live = rw0 < n_q;
     const int last_row = min(q0 + p.rows_per_wg, n_q) - 1;
     const int max_key = min(last_row + shift, n_k - 1);  // last key any row here can see
-    const int nt = max_key >= 0 ? max_key / kBN + 1 : 0;
+    const int nt_all = max_key >= 0 ? max_key / kBN + 1 : 0;
+    const int t_begin = split * p.tiles_per_split;
+    const int nt = min(nt_all, t_begin + p.tiles_per_split);  // this split covers tiles t_begin .. nt-1
 
     // ---- Q fragments: B operand of S^T, lane (r, h) holds Q[row r][16s + 8h .. +7] ----
     bf16x8 qf[8];
@@ -152,15 +163,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     };
 
     int phys_next = 0;  // table entry of tile t+1 while tile t is computed
-    if (nt > 0) stage(0, table_entry(0));
-    if (nt > 1) phys_next = table_entry(1);
+    if (t_begin < nt) stage(t_begin, table_entry(t_begin));
+    if (t_begin + 1 < nt) phys_next = table_entry(t_begin + 1);
 
     const int i16 = lane & 15;
     const int g16 = (lane >> 4) & 1;
     const int qpos = rw0 + r + shift;               // last visible key of this lane's query row
     const int wave_last_key = min(rw0 + 31, n_q - 1) + shift;  // last key any row of the wave sees
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t_begin; t < nt; ++t) {
         // tile t has landed for every wave, and every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -253,12 +264,50 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         }
     }
 
-    // ---- epilogue: O = O^T / l ; lane (r, h) holds dims d*32 + 8*(i>>2) + 4h + (i&3) ----
+    // ---- epilogue ----
+    // Lane (r, h) holds row rw0 + r, dims d*32 + 8*(i>>2) + 4h + (i&3) of O^T: stored as it
+    // stands every store instruction would touch 32 rows.  The tile buffers are free now,
+    // so each wave transposes through its own LDS area (32 rows x 256 B, row stride 272 B:
+    // conflict-free both ways) and writes whole 256-byte row segments, 4 rows per instruction.
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const int row = rw0 + r;
-    if (!wave_live || row >= n_q) return;
+    __syncthreads();  // every wave is done reading K/V tiles
+    if (!wave_live) return;
+    unsigned char* stg = lds + wave * (32 * 272);
+    const int rows_here = n_q - rw0;  // rows of this wave that exist (>= 1)
+    auto flush = [&](unsigned char* gbase, int64_t row_bytes) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rr = 4 * it + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * 272 + (lane & 15) * 16);
+            if (rr < rows_here) *reinterpret_cast<uint4*>(gbase + rr * row_bytes + (lane & 15) * 16) = v;
+        }
+    };
+    if (p.nsplit > 1) {
+        // unnormalised state of this key range; an empty range leaves l = 0 and is skipped
+        // by the merge, so its accumulators need not be written
+        float* dst0 = p.part + (((int64_t)(q_begin + rw0) * p.H_q + hq) * p.nsplit + split) * kPartStride;
+        const int64_t row_bytes = (int64_t)p.H_q * p.nsplit * kPartStride * 4;
+        if (h == 0 && r < rows_here) {
+            float* dst = dst0 + (int64_t)r * (row_bytes / 4);
+            dst[kHeadDim] = m_run;
+            dst[kHeadDim + 1] = l_tot;
+        }
+        if (t_begin >= nt) return;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {  // 64 fp32 dims = 256 B per pass
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 2 * half + dd;
+                    *reinterpret_cast<float4*>(stg + r * 272 + (dd * 32 + 8 * g + 4 * h) * 4) =
+                        make_float4(oacc[d][4 * g], oacc[d][4 * g + 1], oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+                }
+            flush(reinterpret_cast<unsigned char*>(dst0) + half * 256, row_bytes);
+        }
+        return;
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    __bf16* op = p.o + (int64_t)(q_begin + row) * p.o_stride + (int64_t)hq * kHeadDim;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -266,13 +315,105 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
             uint2 w;
             w.x = pack_bf16(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv);
             w.y = pack_bf16(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + d * 32 + 8 * g + 4 * h) = w;
+            *reinterpret_cast<uint2*>(stg + r * 272 + (d * 32 + 8 * g + 4 * h) * 2) = w;
         }
+    flush(reinterpret_cast<unsigned char*>(p.o + (int64_t)(q_begin + rw0) * p.o_stride + (int64_t)hq * kHeadDim),
+          p.o_stride * 2);
+}
+
+// Combine the key-range states of one query row: block = 8 (row, head) pairs x 32 threads
+// (4 dims each).  grid = (ceil(max_seqlen_q * H_q / 8), B).
+__global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const PrefillParams p) {
+    const int b = blockIdx.y;
+    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int row = pair / p.H_q;
+    const int d4 = threadIdx.x & 31;
+    const int q_begin = p.cu_q[b];
+    const int n_q = p.cu_q[b + 1] - q_begin;
+    if (row >= n_q || (p.skip_single && n_q == 1)) return;
+    {
+        const int hq = pair - row * p.H_q;
+        const float* base = p.part + ((int64_t)(q_begin + row) * p.H_q + hq) * p.nsplit * kPartStride;
+        float mmax = kRunInit;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float2 ml = *reinterpret_cast<const float2*>(base + s * kPartStride + kHeadDim);
+            if (ml.y > 0.f) mmax = fmaxf(mmax, ml.x);
+        }
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float den = 0.f;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float2 ml = *reinterpret_cast<const float2*>(base + s * kPartStride + kHeadDim);
+            if (!(ml.y > 0.f)) continue;
+            const float4 a = *reinterpret_cast<const float4*>(base + s * kPartStride + 4 * d4);
+            const float f = __builtin_amdgcn_exp2f(ml.x - mmax);
+            num.x += a.x * f;
+            num.y += a.y * f;
+            num.z += a.z * f;
+            num.w += a.w * f;
+            den += ml.y * f;
+        }
+        const float r = den > 0.f ? 1.0f / den : 0.f;
+        uint2 w;
+        w.x = pack_bf16(num.x * r, num.y * r);
+        w.y = pack_bf16(num.z * r, num.w * r);
+        __bf16* o = p.o + (int64_t)(q_begin + row) * p.o_stride + (int64_t)hq * kHeadDim;
+        *reinterpret_cast<uint2*>(o + 4 * d4) = w;
+    }
 }
 
 static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 
+struct PrefillShape {
+    int nw, hpw, rows_per_wg, n_qtiles, wg_per_pair, n_pairs;
+    int64_t grid_base;
+    int nsplit, tiles_per_split;
+};
+
+// Workgroup shape and key-range split of a launch.  The key range is split only when the
+// launch would leave most CUs without a workgroup (one long sequence prefilled in chunks)
+// and every split still gets a few tiles.
+static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, int max_seqlen_k) {
+    PrefillShape sh;
+    const int G = H_q / H_kv;
+    sh.nw = 4;
+    sh.hpw = gcd_int(G, sh.nw);
+    sh.rows_per_wg = 32 * (sh.nw / sh.hpw);
+    sh.n_qtiles = (max_seqlen_q + sh.rows_per_wg - 1) / sh.rows_per_wg;
+    sh.wg_per_pair = sh.n_qtiles * (G / sh.hpw);
+    sh.n_pairs = B * H_kv;
+    sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+    const int tiles = (max_seqlen_k + kBN - 1) / kBN;
+    int ns = 1;
+    const char* se = getenv("NV_PREFILL_SPLIT");  // forces the split count: a tuning aid
+    if (se && atoi(se) > 0) {
+        ns = atoi(se);
+    } else {
+        const int64_t wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
+        const int64_t target = 512;  // two workgroups per CU
+        if (wgs * 2 <= target) ns = (int)(target / wgs);
+        const int max_by_len = tiles / 16;  // at least 16 tiles (1024 keys) per split
+        if (ns > max_by_len) ns = max_by_len;
+    }
+    if (ns > tiles) ns = tiles;
+    if (ns < 1) ns = 1;
+    sh.tiles_per_split = (tiles + ns - 1) / ns;
+    if (sh.tiles_per_split < 1) sh.tiles_per_split = 1;
+    sh.nsplit = ns > 1 ? (tiles + sh.tiles_per_split - 1) / sh.tiles_per_split : 1;
+    return sh;
+}
+
 }  // namespace nv
+
+extern "C" int64_t nv_attn_prefill_workspace_bytes(int B, int total_q, int max_seqlen_q,
+                                                  int max_seqlen_k, int H_q, int H_kv, int D) {
+    using namespace nv;
+    if (B <= 0 || total_q <= 0 || max_seqlen_q <= 0 || max_seqlen_k < 0 || H_q <= 0 || H_kv <= 0 ||
+        H_q % H_kv != 0 || D != kHeadDim)
+        return 0;
+    const PrefillShape sh = prefill_shape(B, H_q, H_kv, max_seqlen_q, max_seqlen_k);
+    if (sh.nsplit == 1) return 16;
+    return (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
+}
 
 extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const void* v_cache,
                                       void* o, const int32_t* cu_seqlens_q,
@@ -280,27 +421,30 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
                                       int B, int max_blocks, int max_seqlen_q, int max_seqlen_k,
                                       int H_q, int H_kv, int D, int64_t num_blocks, int block_size,
                                       float scale, int64_t q_stride_t, int64_t o_stride_t,
-                                      int skip_single_query, void* stream) {
+                                      int skip_single_query, int total_q, void* workspace,
+                                      int64_t workspace_bytes, void* stream) {
     using namespace nv;
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_q >= 0 && max_seqlen_k >= 0 && H_q > 0 &&
-                   H_kv > 0 && num_blocks > 0 && block_size > 0,
+                   H_kv > 0 && num_blocks > 0 && block_size > 0 && total_q >= 0,
                NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: bad sizes B=%d max_q=%d max_k=%d", B,
                max_seqlen_q, max_seqlen_k);
     NV_REQUIRE(D == kHeadDim, NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: head_dim %d (128 only)", D);
     NV_REQUIRE(H_q % H_kv == 0, NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: H_q %% H_kv != 0");
     NV_REQUIRE(block_size % kBN == 0, NV_ERR_UNSUPPORTED,
                "nv_attn_prefill_varlen: block_size %d must be a multiple of %d", block_size, kBN);
-    if (B == 0 || max_seqlen_q == 0) return NV_OK;
+    if (B == 0 || max_seqlen_q == 0 || total_q == 0) return NV_OK;
     NV_REQUIRE(q && k_cache && v_cache && o && cu_seqlens_q && cu_seqlens_k && block_tables,
                NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: null pointer");
-    NV_REQUIRE(q_stride_t % 8 == 0 && o_stride_t % 4 == 0 && q_stride_t >= (int64_t)H_q * D &&
+    NV_REQUIRE(q_stride_t % 8 == 0 && o_stride_t % 8 == 0 && q_stride_t >= (int64_t)H_q * D &&
                    o_stride_t >= (int64_t)H_q * D,
                NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: bad token strides");
-    NV_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)o) % 16 == 0,
+    NV_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)o |
+                (uintptr_t)workspace) % 16 == 0,
                NV_ERR_INVALID_ARG, "nv_attn_prefill_varlen: pointers must be 16-byte aligned");
     NV_REQUIRE((int64_t)max_blocks * block_size >= max_seqlen_k, NV_ERR_INVALID_ARG,
                "nv_attn_prefill_varlen: block table too narrow for max_seqlen_k");
 
+    const PrefillShape sh = prefill_shape(B, H_q, H_kv, max_seqlen_q, max_seqlen_k);
     PrefillParams p;
     p.q = (const uint4*)q;
     p.k_cache = (const uint4*)k_cache;
@@ -314,19 +458,34 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.H_q = H_q;
     p.H_kv = H_kv;
     p.block_size = block_size;
-    const int G = H_q / H_kv;
-    p.hpw = gcd_int(G, 4);
-    p.rows_per_wg = 32 * (4 / p.hpw);
-    p.n_qtiles = (max_seqlen_q + p.rows_per_wg - 1) / p.rows_per_wg;
-    p.wg_per_pair = p.n_qtiles * (G / p.hpw);
-    p.n_pairs = B * H_kv;
+    p.hpw = sh.hpw;
+    p.rows_per_wg = sh.rows_per_wg;
+    p.n_qtiles = sh.n_qtiles;
+    p.wg_per_pair = sh.wg_per_pair;
+    p.n_pairs = sh.n_pairs;
     p.num_blocks = num_blocks;
     p.q_stride_vec = q_stride_t / 8;
     p.o_stride = o_stride_t;
     p.scale_log2 = scale * 1.4426950408889634f;
     p.skip_single = skip_single_query;
-    const int64_t grid = (int64_t)((p.n_pairs + 7) / 8) * 8 * p.wg_per_pair;
+    p.part = (float*)workspace;
+    p.nsplit = sh.nsplit;
+    p.tiles_per_split = sh.tiles_per_split;
+    p.grid_base = (int)sh.grid_base;
+    if (sh.nsplit > 1) {
+        const int64_t need = (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
+        NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,
+                   "nv_attn_prefill_varlen: workspace %lld bytes < required %lld",
+                   (long long)workspace_bytes, (long long)need);
+    }
+    const int64_t grid = sh.grid_base * sh.nsplit;
     NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, p);
-    return check_launch("nv_attn_prefill_varlen");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+    int rc = check_launch("nv_attn_prefill_varlen");
+    if (rc != NV_OK || sh.nsplit == 1) return rc;
+    hipLaunchKernelGGL(attn_prefill_merge_kernel,
+                       dim3((unsigned)(((int64_t)max_seqlen_q * H_q + 7) / 8), (unsigned)B),
+                       dim3(256), 0, st, p);
+    return check_launch("nv_attn_prefill_varlen(merge)");
 }

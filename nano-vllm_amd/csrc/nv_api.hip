@@ -27,4 +27,4 @@ extern "C" const char* nv_strerror(int code) {
     }
 }
 
-extern "C" int nv_abi_version(void) { return 1; }
+extern "C" int nv_abi_version(void) { return 2; }

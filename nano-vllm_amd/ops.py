@@ -136,12 +136,16 @@ def attn_prefill_varlen(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
         _gpu_bf16(out, "out")
         _rows_ok(out, "out")
         _need(out.shape == q.shape, "out shape != q shape")
-    rc = _lib.lib().nv_attn_prefill_varlen(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-                                           out.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(),
-                                           block_tables.data_ptr(), B, block_tables.shape[1],
-                                           int(max_seqlen_q), int(max_seqlen_k), hq, hkv, d, nb, bs,
-                                           float(scale), q.stride(0), out.stride(0),
-                                           1 if skip_single_query else 0, _stream(q))
+    dll = _lib.lib()
+    need = dll.nv_attn_prefill_workspace_bytes(B, q.shape[0], int(max_seqlen_q), int(max_seqlen_k), hq, hkv, d)
+    ws = _workspace(q.device, need)
+    rc = dll.nv_attn_prefill_varlen(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                    out.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(),
+                                    block_tables.data_ptr(), B, block_tables.shape[1],
+                                    int(max_seqlen_q), int(max_seqlen_k), hq, hkv, d, nb, bs,
+                                    float(scale), q.stride(0), out.stride(0),
+                                    1 if skip_single_query else 0, q.shape[0], ws.data_ptr(), ws.numel(),
+                                    _stream(q))
     _lib.check(rc, "nv_attn_prefill_varlen")
     return out
 

@@ -332,6 +332,34 @@ def test_prefill_against_oracle(hip, H_q, H_kv, n_qs, n_ks):
     _attn_check(_run_attention(ops, pd, "mixed"), ref, "mixed")
 
 
+def test_prefill_key_range_split_long_chunk(hip):
+    """One long sequence prefilled in a chunk: too few workgroups for the chip, so the launch splits
+    the key range over several workgroups and merges their states in a second launch."""
+    _, ops = hip
+    from nanovllm_amd import _lib
+    H_q, H_kv, n_q, n_k = 32, 8, 512, 4096
+    assert _lib.lib().nv_attn_prefill_workspace_bytes(1, n_q, n_q, n_k, H_q, H_kv, 128) > 16   # the split path is taken
+    p = make_paged_problem(21, [n_q], [n_k], H_q, H_kv, 256, 17)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-split")
+
+
+@pytest.mark.parametrize("nsplit", [2, 3, 7])
+def test_prefill_forced_key_range_split_ragged(hip, monkeypatch, nsplit):
+    """Forced split counts on a ragged mixed batch: splits that lie wholly above a row block's
+    diagonal are empty, sequences with one query stay with the decode kernel."""
+    _, ops = hip
+    n_qs, n_ks = [1, 70, 300, 5, 129], [40, 70, 700, 261, 1000]
+    p = make_paged_problem(31, n_qs, n_ks, 16, 8, 256, 12)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    monkeypatch.setenv("NV_PREFILL_SPLIT", str(nsplit))
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, f"prefill-split{nsplit}")
+    _attn_check(_run_attention(ops, pd, "mixed"), ref, f"mixed-split{nsplit}")
+
+
 def test_prefill_block_size_64_and_strided_q(hip):
     _, ops = hip
     p = make_paged_problem(77, [100, 260], [164, 260], 8, 2, 64, 9)

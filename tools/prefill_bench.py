@@ -61,10 +61,14 @@ def main():
         vc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
         o = torch.empty_like(q)
 
+        ws = torch.empty(max(16, dll.nv_attn_prefill_workspace_bytes(B, T, max(n_qs), max(n_ks), H_q, H_kv, D)),
+                         dtype=torch.uint8, device=dev)
+
         def launch():
             rc = dll.nv_attn_prefill_varlen(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), cu_q.data_ptr(),
                                             cu_k.data_ptr(), bt.data_ptr(), B, width, max(n_qs), max(n_ks), H_q, H_kv, D,
-                                            NB, bs, D ** -0.5, q.stride(0), o.stride(0), 0, stream)
+                                            NB, bs, D ** -0.5, q.stride(0), o.stride(0), 0, T, ws.data_ptr(), ws.numel(),
+                                            stream)
             assert rc == 0, dll.nv_last_error()
 
         launch()
