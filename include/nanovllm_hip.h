@@ -116,6 +116,15 @@ NV_API int nv_rmsnorm(const void* x, const void* w, void* y, int64_t rows, int c
                int64_t x_stride, float eps, void* stream);
 
 /*
+ * SiluAndMul.  Replaces SiluAndMul.forward, nanovllm/layers/activation.py:10-16, as its
+ * compiled form evaluates it:  y[r, j] = bf16( silu(f32(x[r, j])) * f32(x[r, inter + j]) ).
+ * x: [rows, 2*inter] bf16 with row stride x_stride elements; y: [rows, inter] contiguous.
+ * inter must be a multiple of 8.
+ */
+NV_API int nv_silu_and_mul(const void* x, void* y, int64_t rows, int inter, int64_t x_stride,
+                    void* stream);
+
+/*
  * Fused residual add + RMSNorm.  Replaces RMSNorm.forward with residual,
  * nanovllm/layers/layernorm.py:88-100:
  *   s = f32(x) + f32(res);  new_res = bf16(s);  y = bf16( s * rsqrt(mean(s^2)+eps) * f32(w) )

@@ -28,6 +28,7 @@ PROTOTYPES = {
     "nv_attn_prefill_varlen": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                       _i32, _i32, _i64, _i32, _f32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "nv_rmsnorm": (_i32, [_vp, _vp, _vp, _i64, _i32, _i64, _f32, _vp]),
+    "nv_silu_and_mul": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp]),
     "nv_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "nv_rope": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "nv_qknorm_rope_store": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,

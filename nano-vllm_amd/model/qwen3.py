@@ -66,9 +66,10 @@ class ModelConfig:
 
 def _default_layers():
     from .. import layers as _pkg  # noqa: F401
-    from ..layers import attention, layernorm, rope
+    from ..layers import activation, attention, layernorm, rope
 
     class _L:
+        SiluAndMul = activation.SiluAndMul
         Attention = attention.Attention
         RMSNorm = layernorm.RMSNorm
         make_rope = staticmethod(rope.make_rope)
@@ -143,8 +144,9 @@ class Qwen3Attention(nn.Module):
 
 
 class Qwen3MLP(nn.Module):
-    def __init__(self, cfg: ModelConfig):
+    def __init__(self, cfg: ModelConfig, L):
         super().__init__()
+        self.act_fn = L.SiluAndMul()
         self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
         self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=False)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=False)
@@ -160,17 +162,15 @@ class Qwen3MLP(nn.Module):
     def forward(self, x):
         w = getattr(self, "_gate_up_weight", None)
         if w is not None and w.device == x.device and w.dtype == x.dtype:
-            gu = F.linear(x, w)
-            n = w.shape[0] // 2
-            return self.down_proj(F.silu(gu[:, :n]) * gu[:, n:])
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+            return self.down_proj(self.act_fn(F.linear(x, w)))
+        return self.down_proj(self.act_fn(torch.cat([self.gate_proj(x), self.up_proj(x)], dim=-1)))
 
 
 class Qwen3DecoderLayer(nn.Module):
     def __init__(self, cfg: ModelConfig, L, fused: bool):
         super().__init__()
         self.self_attn = Qwen3Attention(cfg, L, fused)
-        self.mlp = Qwen3MLP(cfg)
+        self.mlp = Qwen3MLP(cfg, L)
         self.input_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 

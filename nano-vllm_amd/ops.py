@@ -150,6 +150,20 @@ def attn_prefill_varlen(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
     return out
 
 
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    """y = bf16(silu(f32(gate)) * f32(up)) for x = [gate | up] along the last dimension."""
+    _need(x.is_cuda, "x must be a GPU tensor (this path has no CPU implementation)")
+    _need(x.dtype == _BF16, f"x must be bfloat16, got {x.dtype}")
+    _need(x.dim() >= 1 and x.shape[-1] % 16 == 0, "last dimension must be a multiple of 16")
+    inter = x.shape[-1] // 2
+    x2 = x.reshape(-1, x.shape[-1])
+    _need(x2.stride(1) == 1 and x2.stride(0) % 8 == 0, "rows must be contiguous with a stride that is a multiple of 8")
+    y = torch.empty(x.shape[:-1] + (inter,), dtype=_BF16, device=x.device)
+    rc = _lib.lib().nv_silu_and_mul(x2.data_ptr(), y.data_ptr(), x2.shape[0], inter, x2.stride(0), _stream(x))
+    _lib.check(rc, "nv_silu_and_mul")
+    return y
+
+
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     """y = bf16(f32(x) * rsqrt(mean(x^2) + eps) * f32(w)) over the last dimension."""
     _gpu_bf16(x, "x")

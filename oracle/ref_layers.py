@@ -1,6 +1,7 @@
-"""Oracle (test infrastructure): RMSNorm and rotary embedding in plain torch on the CPU.
+"""Oracle (test infrastructure): RMSNorm, rotary embedding and SiluAndMul in plain torch on the CPU.
 
-Follows nanovllm/layers/layernorm.py:79-100 and nanovllm/layers/rope.py:5-56 of the reference.
+Follows nanovllm/layers/layernorm.py:79-100, nanovllm/layers/rope.py:5-56 and
+nanovllm/layers/activation.py:10-16 of the reference.
 """
 from __future__ import annotations
 
@@ -19,6 +20,14 @@ def rmsnorm_ref(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: tor
     r = torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)   # :95
     y = (xf * r * weight.float()).to(dt)                           # :96-98, single rounding
     return (y, new_res) if residual is not None else y
+
+
+def silu_and_mul_ref(x: torch.Tensor) -> torch.Tensor:
+    """SiluAndMul.forward (activation.py:10-16) as its compiled form evaluates it: the halves of
+    the last dimension in fp32, silu(gate) * up, one rounding to the input dtype."""
+    d = x.shape[-1] // 2
+    g, u = x[..., :d].float(), x[..., d:].float()
+    return (g * torch.sigmoid(g) * u).to(x.dtype)
 
 
 def rmsnorm_ref_eager(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: torch.Tensor | None = None):

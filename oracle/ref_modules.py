@@ -58,6 +58,11 @@ class Rope(nn.Module):
         return ref_layers.rope_ref(positions, query, key, self.cos_sin_cache)
 
 
+class SiluAndMul(nn.Module):
+    def forward(self, x):
+        return ref_layers.silu_and_mul_ref(x)
+
+
 _ropes: dict = {}
 
 

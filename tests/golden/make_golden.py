@@ -16,6 +16,7 @@ cross-checked here against the reference's dense SDPA helper where that helper i
 Fixtures (bf16 tensors are stored as their int16 bit patterns):
   g1_store.npz    Attention.store_kvcache                       (reference output)
   g2_rmsnorm.npz  RMSNorm.forward compiled, with/without residual, hidden and per-head (reference)
+  g7_silu.npz     SiluAndMul.forward compiled (reference)
   g3_rope.npz     RotaryPositionEmbedding.forward                (reference output)
   g4_attention.npz  paged varlen attention cases                 (oracle; cross-checked)
   g5_hash.json    BlockManager.compute_hash known answers        (reference output)
@@ -269,10 +270,31 @@ def g6_paging(ref):
     print("  g6 end: free", trace["free_blocks_at_end"], "cached", trace["cached_hashes_at_end"])
 
 
+def g7_silu(ref):
+    from nanovllm.layers.activation import SiluAndMul
+    from oracle.ref_layers import silu_and_mul_ref
+    g = torch.Generator().manual_seed(707)
+    mod = SiluAndMul()
+    out = {}
+    for tag, shape, amp in (("mlp", (48, 2 * 3072), 2.0), ("small", (3, 2 * 64), 1.0), ("large_values", (16, 2 * 512), 12.0)):
+        x = (torch.randn(*shape, generator=g, dtype=torch.float32) * amp).bfloat16()
+        with torch.no_grad():
+            y = mod(x.clone())                                       # compiled forward (Inductor, CPU)
+        yo = silu_and_mul_ref(x)
+        mism = (y.view(torch.int16) != yo.view(torch.int16)).sum().item()
+        print(f"  g7[{tag}] oracle vs compiled reference: {mism}/{y.numel()} mismatching elements")
+        out.update({f"{tag}_x": bits(x), f"{tag}_y": bits(y)})
+    np.savez(os.path.join(HERE, "g7_silu.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     ref = import_reference()
-    for fn in (g1_store, g3_rope, g4_attention, g5_hash, g6_paging, g2_rmsnorm):
+    every = (g1_store, g3_rope, g4_attention, g5_hash, g6_paging, g2_rmsnorm, g7_silu)
+    wanted = sys.argv[1:]                     # e.g. "g7_silu": regenerate only that fixture
+    for fn in every:
+        if wanted and fn.__name__ not in wanted:
+            continue
         print(fn.__name__)
         fn(ref)
     print("done")

@@ -131,6 +131,38 @@ def test_rmsnorm_module_and_input_preserved(hip):
     assert torch.equal(bits(nr.cpu()), bits(want_nr))
 
 
+# ------------------------------------------------------------------ SiluAndMul
+def _check_silu(y, want, name):
+    """The kernel's exp differs from the host's in the last fp32 bits: rare flips of one bf16 ulp."""
+    mism = bits(y) != bits(want)
+    assert mism.float().mean().item() <= 5e-3, (name, mism.float().mean().item())
+    yf, wf = y.float(), want.float()
+    assert ((yf - wf).abs() <= wf.abs() * 2 ** -7 + 1e-30).all(), name
+
+
+def test_silu_and_mul_matches_compiled_reference_fixture(hip, golden):
+    nv, ops = hip
+    from nanovllm_amd.layers.activation import SiluAndMul
+    g = golden("g7_silu.npz")
+    for tag in ("mlp", "small", "large_values"):
+        x = bf16(g[f"{tag}_x"]).to(DEV)
+        y = SiluAndMul()(x)
+        assert y.shape == (x.shape[0], x.shape[1] // 2)
+        _check_silu(y.cpu(), bf16(g[f"{tag}_y"]), tag)
+
+
+@pytest.mark.parametrize("rows,inter", [(1, 8), (256, 3072), (7, 12288), (300, 1024)])
+def test_silu_and_mul_shapes_and_strides_against_oracle(hip, rows, inter):
+    _, ops = hip
+    g = torch.Generator().manual_seed(rows + inter)
+    wide = (torch.randn(rows, 2 * inter + 64, generator=g) * 3).bfloat16()
+    wide[0, 0] = -200.0                                            # exp overflow side: result must be -0 * up
+    x = wide[:, :2 * inter]                                        # row stride larger than the row
+    y = ops.silu_and_mul(x.to(DEV)[:, :]) if rows == 1 else ops.silu_and_mul(wide.to(DEV)[:, :2 * inter])
+    _check_silu(y.cpu(), ref_layers.silu_and_mul_ref(x), "strided")
+    assert torch.isfinite(y.float()).all()
+
+
 # ------------------------------------------------------------------ rotary embedding
 def test_rope_matches_reference_fixture(hip, golden):
     nv, _ = hip

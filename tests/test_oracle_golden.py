@@ -33,6 +33,13 @@ def test_rmsnorm_matches_compiled_reference(golden):
             assert (got.float() - want.float()).abs().max().item() <= 2e-2 * max(1.0, want.float().abs().max().item())
 
 
+def test_silu_and_mul_matches_compiled_reference(golden):
+    g = golden("g7_silu.npz")
+    for tag in ("mlp", "small", "large_values"):
+        y = ref_layers.silu_and_mul_ref(bf16(g[f"{tag}_x"]))
+        assert torch.equal(bits(y), torch.from_numpy(g[f"{tag}_y"])), tag          # bit exact
+
+
 def test_rmsnorm_eager_form_is_within_one_ulp(golden):
     g = golden("g2_rmsnorm.npz")
     x, w = bf16(g["hidden_x"]), bf16(g["hidden_w"])
