@@ -122,7 +122,13 @@ class ModelRunner:
     # ---- KV cache -------------------------------------------------------------------------
     def block_bytes(self) -> int:
         c = self.cfg
-        return 2 * c.num_hidden_layers * self.block_size * c.num_key_value_heads * c.head_dim * self.dtype.itemsize
+        return 2 * c.num_hidden_layers * self.block_size * self.local_kv_heads * c.head_dim * self.dtype.itemsize
+
+    @property
+    def local_kv_heads(self) -> int:
+        """kv heads whose cache this rank holds (all of them unless the model is head-sharded)."""
+        shard = getattr(self.model, "shard", None)
+        return shard.local_kv_heads if shard is not None else self.cfg.num_key_value_heads
 
     def init_kv_cache(self, num_blocks: int | None, utilization: float) -> int:
         c = self.cfg
@@ -133,7 +139,7 @@ class ModelRunner:
             budget = int(total * utilization) - (total - free)
             num_blocks = budget // self.block_bytes()
         assert num_blocks > 0, "no memory left for the KV cache"
-        self.kv_cache = torch.empty(2, c.num_hidden_layers, num_blocks, self.block_size, c.num_key_value_heads,
+        self.kv_cache = torch.empty(2, c.num_hidden_layers, num_blocks, self.block_size, self.local_kv_heads,
                                     c.head_dim, dtype=self.dtype, device=self.device)
         layer = 0
         for module in self.model.modules():

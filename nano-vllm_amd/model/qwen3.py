@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..parallel import all_gather_heads
+
 from ..utils.cache_context import get_context
 
 
@@ -87,15 +89,22 @@ def _hip_fused(positions, q, k, v, q_w, k_w, rope, eps, attn):
 
 
 class Qwen3Attention(nn.Module):
-    def __init__(self, cfg: ModelConfig, L, fused: bool):
+    """With `shard` (a parallel.HeadShard) the module owns only this rank's kv heads and their query
+    heads: q/k/v_proj hold the matching rows, the KV cache has H_kv/N heads, and the head outputs
+    of all ranks are all-gathered before the (replicated) o_proj."""
+
+    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
         super().__init__()
-        self.num_heads, self.num_kv_heads, self.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        self.shard, self.group = shard, group
+        self.head_dim = cfg.head_dim
+        self.num_heads = shard.local_heads if shard else cfg.num_attention_heads
+        self.num_kv_heads = shard.local_kv_heads if shard else cfg.num_key_value_heads
         self.q_size, self.kv_size = self.num_heads * self.head_dim, self.num_kv_heads * self.head_dim
         self.eps = cfg.rms_norm_eps
         self.q_proj = nn.Linear(cfg.hidden_size, self.q_size, bias=cfg.attention_bias)
         self.k_proj = nn.Linear(cfg.hidden_size, self.kv_size, bias=cfg.attention_bias)
         self.v_proj = nn.Linear(cfg.hidden_size, self.kv_size, bias=cfg.attention_bias)
-        self.o_proj = nn.Linear(self.q_size, cfg.hidden_size, bias=cfg.attention_bias)
+        self.o_proj = nn.Linear(cfg.num_attention_heads * self.head_dim, cfg.hidden_size, bias=cfg.attention_bias)
         self.rope = L.make_rope(self.head_dim, cfg.max_position_embeddings, cfg.rope_theta, cfg.rope_scaling)
         self.qk_norm = cfg.qk_norm
         if cfg.qk_norm:
@@ -140,7 +149,9 @@ class Qwen3Attention(nn.Module):
                 q, k = self.q_norm(q), self.k_norm(k)
             q, k = self.rope(positions, q, k)
             o = self.attention(q, k, v)
-        return self.o_proj(o.reshape(-1, self.q_size))
+        if self.shard is not None and self.shard.world > 1:
+            o = all_gather_heads(o.reshape(-1, self.num_heads, self.head_dim), self.shard, self.group)
+        return self.o_proj(o.reshape(o.shape[0], -1))
 
 
 class Qwen3MLP(nn.Module):
@@ -167,9 +178,9 @@ class Qwen3MLP(nn.Module):
 
 
 class Qwen3DecoderLayer(nn.Module):
-    def __init__(self, cfg: ModelConfig, L, fused: bool):
+    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
         super().__init__()
-        self.self_attn = Qwen3Attention(cfg, L, fused)
+        self.self_attn = Qwen3Attention(cfg, L, fused, shard, group)
         self.mlp = Qwen3MLP(cfg, L)
         self.input_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
@@ -186,10 +197,11 @@ class Qwen3DecoderLayer(nn.Module):
 
 
 class Qwen3Model(nn.Module):
-    def __init__(self, cfg: ModelConfig, L, fused: bool):
+    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
         super().__init__()
         self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
-        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, L, fused) for _ in range(cfg.num_hidden_layers))
+        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, L, fused, shard, group)
+                                    for _ in range(cfg.num_hidden_layers))
         self.norm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 
     def forward(self, input_ids, positions):
@@ -203,14 +215,33 @@ class Qwen3Model(nn.Module):
 
 
 class Qwen3ForCausalLM(nn.Module):
-    def __init__(self, cfg: ModelConfig, layers=None, fused: bool = True):
+    def __init__(self, cfg: ModelConfig, layers=None, fused: bool = True, shard=None, group=None):
+        """shard: optional parallel.HeadShard of this rank (attention sharded by kv head over the
+        ranks of `group`, everything else replicated)."""
         super().__init__()
         L = layers if layers is not None else _default_layers()
-        self.config = cfg
-        self.model = Qwen3Model(cfg, L, fused and hasattr(L, "fused_qknorm_rope_store"))
+        self.config, self.shard = cfg, shard
+        if shard is not None and (shard.num_heads, shard.num_kv_heads) != (cfg.num_attention_heads,
+                                                                             cfg.num_key_value_heads):
+            raise ValueError("HeadShard head counts do not match the model config")
+        self.model = Qwen3Model(cfg, L, fused and hasattr(L, "fused_qknorm_rope_store"), shard, group)
         self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
         if cfg.tie_word_embeddings:
             self.lm_head.weight = self.model.embed_tokens.weight
+
+    def load_full_state_dict(self, full: dict) -> None:
+        """Load an unsharded state dict: with a shard, q/k/v_proj take the rows of this rank's heads."""
+        sh, d = self.shard, self.config.head_dim
+        sd = {}
+        for name, t in full.items():
+            if sh is not None and ".self_attn." in name:
+                part = name.rsplit(".", 2)[-2]
+                if part == "q_proj":
+                    t = t[sh.q_heads.start * d:sh.q_heads.stop * d]
+                elif part in ("k_proj", "v_proj"):
+                    t = t[sh.kv_heads.start * d:sh.kv_heads.stop * d]
+            sd[name] = t
+        self.load_state_dict(sd)
 
     def fuse_weights(self) -> "Qwen3ForCausalLM":
         """Fuse the q/k/v and gate/up projection weights of every layer (after weights are loaded and

@@ -57,6 +57,50 @@ def test_head_sharded_attention_all_gather_world2(tmp_path, H_q, H_kv):
     assert open(path).read() == "ok"
 
 
+def _engine_worker(rank, world, port, result_path):
+    """Every rank runs the same scheduler on the same requests (replicated control plane) with a
+    head-sharded model; the generated tokens must equal those of the unsharded model."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nanovllm_amd.engine.llm_engine import LLMEngine
+        from nanovllm_amd.engine.sequence import SamplingParams
+        from nanovllm_amd.model.qwen3 import ModelConfig, Qwen3ForCausalLM
+        from oracle import ref_modules
+        cfg = ModelConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                          num_attention_heads=8, num_key_value_heads=4, head_dim=128, max_position_embeddings=1024)
+        torch.manual_seed(7)
+        full = Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False).to(torch.bfloat16)
+        for prm in full.parameters():
+            torch.nn.init.normal_(prm, 0.0, 0.05)
+        shard = HeadShard(rank, world, cfg.num_attention_heads, cfg.num_key_value_heads)
+        part = Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False, shard=shard).to(torch.bfloat16)
+        part.load_full_state_dict(full.state_dict())
+        g = torch.Generator().manual_seed(11)
+        prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (16, 45, 70)]
+        kw = dict(block_size=16, num_kvcache_blocks=32, max_num_batched_tokens=64, long_prefill_token_threshold=32,
+                  device="cpu", eos=-1)
+        eng = LLMEngine(part, cfg, **kw)
+        ok = eng.runner.kv_cache.shape[4] == cfg.num_key_value_heads // world
+        outs, _ = eng.generate(prompts, SamplingParams(0.0, 5))
+        ref_outs, _ = LLMEngine(full, cfg, **kw).generate(prompts, SamplingParams(0.0, 5))
+        ok = ok and [o["token_ids"] for o in outs] == [o["token_ids"] for o in ref_outs]
+        flags = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(flags, torch.tensor([1.0 if ok else 0.0]))
+        if rank == 0:
+            with open(result_path, "w") as f:
+                f.write("ok" if all(x.item() == 1.0 for x in flags) else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_head_sharded_model_generates_same_tokens_world2(tmp_path):
+    path = str(tmp_path / "result.txt")
+    mp.spawn(_engine_worker, args=(2, _free_port(), path), nprocs=2, join=True)
+    assert open(path).read() == "ok"
+
+
 def test_head_shard_ranges():
     s = HeadShard(3, 4, 64, 8)
     assert list(s.kv_heads) == [6, 7] and list(s.q_heads) == list(range(48, 64))
