@@ -80,7 +80,8 @@ class LLMEngine:
 
     def generate(self, prompts, sampling_params=None):
         """prompts: list of token-id lists (or strings with a tokenizer).  Returns (outputs, metrics);
-        outputs[i] = {"token_ids": [...], "text": str | None} in prompt order."""
+        outputs[i] = {"token_ids": [...], "text": str | None, "cached_tokens": prompt tokens taken from the
+        prefix cache} in prompt order."""
         if not isinstance(sampling_params, (list, tuple)):
             sampling_params = [sampling_params] * len(prompts)
         seqs = [self.add_request(p, sp) for p, sp in zip(prompts, sampling_params)]
@@ -103,5 +104,5 @@ class LLMEngine:
         outs = []
         for s in seqs:
             text = self.tokenizer.decode(s.output_tokens) if self.tokenizer is not None else None
-            outs.append({"token_ids": list(s.output_tokens), "text": text})
+            outs.append({"token_ids": list(s.output_tokens), "text": text, "cached_tokens": s.num_cached_tokens})
         return outs, metrics

@@ -73,6 +73,7 @@ class Scheduler:
                 break
             bm.allocate_slots(seq, cached_blocks, blocks_needed)
             seq.num_computed_tokens = n_cached
+            seq.num_cached_tokens = n_cached
             seq.num_scheduled_tokens = n_new
             seq.status = SequenceStatus.RUNNING
             bm.publish_full_blocks(seq, n_cached + n_new)

@@ -30,6 +30,7 @@ class Sequence:
         self.prompt_tokens = list(prompt_tokens)
         self.output_tokens: list[int] = []
         self.num_computed_tokens = 0      # tokens whose K/V is in the cache
+        self.num_cached_tokens = 0        # of those, prompt tokens found in the prefix cache at admission
         self.num_scheduled_tokens = 0     # tokens to process in the coming step
         self.block_table: list[int] = []  # physical block ids, logical order
         self.sampling_params = sampling_params or SamplingParams()

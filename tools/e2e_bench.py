@@ -36,13 +36,74 @@ def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device=
                     device=device, eos=-1, use_graphs=graphs)
     g = torch.Generator().manual_seed(seed)
     prompts = [torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist() for _ in range(batch)]
-    # warm-up on a small batch (library load, hipBLASLt heuristics)
-    eng.generate(prompts[:4], SamplingParams(0.0, 4))
-    eng.generate(prompts, SamplingParams(0.0, 2))          # captures the decode graph of the full batch
+    # warm-up (library load, hipBLASLt heuristics, decode-graph capture of the full batch) on OTHER random
+    # prompts, so that the timed run finds nothing of its own in the prefix cache
+    warm = [torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist() for _ in range(batch)]
+    eng.generate(warm[:4], SamplingParams(0.0, 4))
+    eng.generate(warm, SamplingParams(0.0, 2))
     torch.cuda.synchronize()
     outs, metrics = eng.generate(prompts, SamplingParams(0.0, out_len))
     s = metrics.summary()
+    s["prefix_cache_hit_tokens"] = int(sum(o.get("cached_tokens", 0) for o in outs))
     s.update(model=model_name, batch=batch, prompt_len=prompt_len, out_len=out_len, fused=fused, graphs=graphs, fuse_gemms=fuse_gemms)
+    return s
+
+
+def _build(model_name, device, seed, fused=True, fuse_gemms=True):
+    cfg = getattr(ModelConfig, model_name)()
+    torch.manual_seed(seed)
+    with torch.device(device):
+        model = Qwen3ForCausalLM(cfg, fused=fused)
+    for name, p in model.named_parameters():
+        if "norm" in name:
+            torch.nn.init.ones_(p)
+        else:
+            torch.nn.init.normal_(p, 0.0, 0.02)
+    model = model.to(torch.bfloat16)
+    return cfg, (model.fuse_weights() if fuse_gemms else model)
+
+
+def run_long_prompt_with_shared_prefix(model_name="qwen3_8b", prompt_len=8192, shared=7936, tail=256, out_len=16,
+                                       device="cuda:0", seed=0):
+    """One long prompt prefilled in 512-token chunks, then a second request that shares its first
+    `shared` tokens (full cache blocks) and adds `tail` new ones: the second must skip the shared part."""
+    cfg, model = _build(model_name, device, seed)
+    eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=2 * (prompt_len // 256) + 16, device=device, eos=-1,
+                    use_graphs=False)
+    g = torch.Generator().manual_seed(seed)
+    warm = torch.randint(0, cfg.vocab_size, (1024,), generator=g).tolist()
+    eng.generate([warm], SamplingParams(0.0, 4))
+    p1 = torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist()
+    p2 = p1[:shared] + torch.randint(0, cfg.vocab_size, (tail,), generator=g).tolist()
+    torch.cuda.synchronize()
+    o1, m1 = eng.generate([p1], SamplingParams(0.0, out_len))
+    o2, m2 = eng.generate([p2], SamplingParams(0.0, out_len))
+    s1, s2 = m1.summary(), m2.summary()
+    return {"model": model_name, "prompt_len": prompt_len, "chunk": 512,
+            "first": {"ttft_s": s1["ttft_max_s"], "prefill_tok_per_s": prompt_len / s1["ttft_max_s"],
+                      "cached_tokens": o1[0]["cached_tokens"], "mean_tpot_ms": s1["mean_tpot_ms"]},
+            "second_shared_prefix": {"ttft_s": s2["ttft_max_s"], "cached_tokens": o2[0]["cached_tokens"],
+                                     "new_prompt_tokens": len(p2) - o2[0]["cached_tokens"],
+                                     "mean_tpot_ms": s2["mean_tpot_ms"]}}
+
+
+def run_long_context_decode(model_name="llama31_8b", batch=8, ctx=32768, out_len=64, device="cuda:0", seed=0):
+    """`batch` sequences whose context reaches `ctx` tokens at the last generated token: prefill in
+    512-token chunks, then `out_len` decode steps at ~32k keys per sequence."""
+    cfg, model = _build(model_name, device, seed)
+    prompt_len = ctx - out_len
+    eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=batch * (ctx // 256 + 1) + 8, device=device,
+                    eos=-1, use_graphs=True)
+    g = torch.Generator().manual_seed(seed)
+    warm = [torch.randint(0, cfg.vocab_size, (600,), generator=g).tolist() for _ in range(batch)]
+    eng.generate(warm, SamplingParams(0.0, 3))
+    prompts = [torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist() for _ in range(batch)]
+    torch.cuda.synchronize()
+    outs, m = eng.generate(prompts, SamplingParams(0.0, out_len))
+    s = m.summary()
+    s.update(model=model_name, batch=batch, ctx=ctx, out_len=out_len,
+             prefill_tok_per_s=batch * prompt_len / s["ttft_max_s"],
+             prefix_cache_hit_tokens=int(sum(o["cached_tokens"] for o in outs)))
     return s
 
 
@@ -55,5 +116,14 @@ if __name__ == "__main__":
     ap.add_argument("--unfused", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fuse-gemms", action="store_true")
+    ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode"])
+    ap.add_argument("--ctx", type=int, default=32768)
     a = ap.parse_args()
+    if a.scenario == "long_prompt":
+        print(json.dumps(run_long_prompt_with_shared_prefix(a.model if a.model != "qwen3_0_6b" else "qwen3_8b")))
+        sys.exit(0)
+    if a.scenario == "long_context_decode":
+        print(json.dumps(run_long_context_decode(a.model if a.model != "qwen3_0_6b" else "llama31_8b",
+                                                 a.batch if a.batch != 256 else 8, a.ctx, a.out_len if a.out_len != 256 else 64)))
+        sys.exit(0)
     print(json.dumps(run(a.model, a.batch, a.prompt_len, a.out_len, fused=not a.unfused, graphs=not a.no_graphs, fuse_gemms=not a.no_fuse_gemms)))
