@@ -484,3 +484,57 @@ def test_full_size_decode_properties(hip):
     bt2 = inv[p["block_tables"].long()].to(torch.int32).to(DEV)
     o2 = ops.attn_decode_paged(pd["q"], k2, v2, pd["cu_k"], bt2, p["max_k"], p["scale"])
     assert torch.equal(o, o2)
+
+
+def test_full_size_prefill_properties(hip):
+    """Config-3 size (H 32/8, one 8192-token sequence, block 256) through size-independent properties:
+    (1) the last 512-token chunk computed alone (keys 0..8191 cached; the key-range split path) equals
+    rows 7680..8191 of the whole-prompt prefill (the unsplit path) within the tolerance; (2) V == const
+    gives const; (3) a sample of rows against the oracle; (4) permuting the physical blocks leaves the
+    output bit-identical."""
+    _, ops = hip
+    H_q, H_kv, n, bs, chunk = 32, 8, 8192, 256, 512
+    NB = n // bs
+    p = make_paged_problem(5, [n], [n], H_q, H_kv, bs, NB, pad_cols=0)
+    pd = to_dev(p)
+    full = _run_attention(ops, pd, "prefill")
+    last = dict(pd, q=pd["q"][n - chunk:].contiguous(), cu_q=torch.tensor([0, chunk], dtype=torch.int32, device=DEV),
+                max_q=chunk)
+    part = _run_attention(ops, last, "prefill")
+    assert (part.float() - full[n - chunk:].float()).abs().max().item() <= TOL
+    rows = [0, 1, 63, 64, 2047, 8191]
+    for r in rows:                                                  # row r alone is a chunk of one query over r+1 keys
+        ref = ref_attention.paged_attention_ref(p["q"][r:r + 1], p["k_cache"], p["v_cache"],
+                                                torch.tensor([0, 1], dtype=torch.int32),
+                                                torch.tensor([0, r + 1], dtype=torch.int32), p["block_tables"], p["scale"])
+        _attn_check(full[r:r + 1], ref, f"full-size prefill row {r}")
+    const = pd["v_cache"].clone().fill_(-1.5)
+    oc = ops.attn_prefill_varlen(pd["q"], pd["k_cache"], const, pd["cu_q"], pd["cu_k"], pd["block_tables"], n, n, p["scale"])
+    assert (oc.float() + 1.5).abs().max().item() <= 8e-3
+    g = torch.Generator().manual_seed(9)
+    perm = torch.randperm(NB, generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(NB)
+    k2, v2 = p["k_cache"][perm].to(DEV), p["v_cache"][perm].to(DEV)
+    bt2 = inv[p["block_tables"].long()].to(torch.int32).to(DEV)
+    o2 = ops.attn_prefill_varlen(pd["q"], k2, v2, pd["cu_q"], pd["cu_k"], bt2, n, n, p["scale"])
+    assert torch.equal(full, o2)
+
+
+def test_unsupported_arguments_raise(hip):
+    """Shapes the kernels are not built for are refused with the library's error text, never run."""
+    _, ops = hip
+    from nanovllm_amd._lib import NanoVllmHipError
+    p = to_dev(make_paged_problem(1, [1, 1], [10, 20], 12, 4, 256, 3))          # 3 query heads per kv head
+    with pytest.raises(NanoVllmHipError, match="H_q/H_kv"):
+        _run_attention(ops, p, "decode")
+    p = to_dev(make_paged_problem(1, [40], [40], 8, 4, 32, 3))                  # prefill needs block_size % 64 == 0
+    with pytest.raises(NanoVllmHipError, match="block_size"):
+        _run_attention(ops, p, "prefill")
+    p = to_dev(make_paged_problem(1, [1], [40], 8, 4, 256, 3, D=64))            # head_dim 64
+    with pytest.raises((NanoVllmHipError, ValueError)):
+        _run_attention(ops, p, "decode")
+    p = to_dev(make_paged_problem(1, [1], [600], 8, 4, 256, 4))
+    p["block_tables"] = p["block_tables"][:, :2].contiguous()                   # table too narrow for 600 keys
+    with pytest.raises(NanoVllmHipError, match="block table"):
+        _run_attention(ops, p, "decode")
