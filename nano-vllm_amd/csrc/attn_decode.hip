@@ -523,29 +523,44 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     }
 }
 
-// Combine the per-chunk partial states of one (sequence, query head): 32 threads, 4 dims each.
+// Combine the per-chunk partial states of one (sequence, query head): 32 threads x 4 dims.
+// SG = 1: a 256-thread block handles 8 pairs, each 32-thread group walks all chunks of its pair
+// (few chunks).  SG = 8: a block handles one pair and its 8 groups walk every 8th chunk, then
+// reduce through LDS (many chunks: the walk is a chain of dependent-latency loads).
+template <int SG>
 __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodeParams p, int H_q) {
-    const int pair = blockIdx.x * 8 + (threadIdx.x >> 5);
+    __shared__ float red_m[8];
+    __shared__ float red_den[8];
+    __shared__ float4 red_num[8][32];
+    const int grp = threadIdx.x >> 5;
     const int d4 = threadIdx.x & 31;
-    if (pair >= p.B * H_q) return;
+    const int pair = SG == 1 ? blockIdx.x * 8 + grp : blockIdx.x;
+    if (pair >= p.B * H_q) return;  // SG == 8: uniform per block; SG == 1: no barriers below
     const int b = pair / H_q;
     const int hq = pair - b * H_q;
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     int tq = b;
     if (p.cu_q) {
-        if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;
+        if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // uniform per block in both forms
         tq = p.cu_q[b];
     }
     int ns = (n_k + p.chunk - 1) / p.chunk;
     ns = ns < 1 ? 1 : ns;  // split 0 always writes a (possibly empty) state
     const float* base = p.part + ((int64_t)b * H_q + hq) * p.nsplit * kPartStride;
+    const int s0 = SG == 1 ? 0 : grp;
     float mmax = kNegBig;
 #pragma unroll 4
-    for (int s = 0; s < ns; ++s) mmax = fmaxf(mmax, base[s * kPartStride + kHeadDim]);
+    for (int s = s0; s < ns; s += SG) mmax = fmaxf(mmax, base[s * kPartStride + kHeadDim]);
+    if (SG > 1) {
+        if (d4 == 0) red_m[grp] = mmax;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) mmax = fmaxf(mmax, red_m[g]);
+    }
     float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
     float den = 0.f;
 #pragma unroll 4
-    for (int s = 0; s < ns; ++s) {
+    for (int s = s0; s < ns; s += SG) {
         const float2 ml = *reinterpret_cast<const float2*>(base + s * kPartStride + kHeadDim);
         const float4 a = *reinterpret_cast<const float4*>(base + s * kPartStride + 4 * d4);
         const float f = __builtin_amdgcn_exp2f(ml.x - mmax);
@@ -554,6 +569,23 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
         num.z += a.z * f;
         num.w += a.w * f;
         den += ml.y * f;
+    }
+    if (SG > 1) {
+        red_num[grp][d4] = num;
+        if (d4 == 0) red_den[grp] = den;
+        __syncthreads();
+        if (grp != 0) return;
+        num = make_float4(0.f, 0.f, 0.f, 0.f);
+        den = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 a = red_num[g][d4];
+            num.x += a.x;
+            num.y += a.y;
+            num.z += a.z;
+            num.w += a.w;
+            den += red_den[g];
+        }
     }
     const float r = den > 0.f ? 1.0f / den : 0.f;
     uint2 w;
@@ -565,7 +597,14 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
 
 // Keys per work item.  Smaller chunks give more, finer-grained waves (better balance on
 // ragged batches, more loads in flight for small batches) at the price of more partials.
-static int choose_chunk(int B, int H_kv, int max_k) {
+// G >= 4 runs the MFMA-score kernel (about 200 registers: one 4-wave workgroup per SIMD set and
+// CU at a time), which measured fastest with one workgroup per CU; the VALU kernel wants two.
+static bool decode_uses_mfma(int G) {
+    const char* ve = getenv("NV_DECODE_VALU");  // 1 keeps G >= 4 on the all-VALU kernel: a comparison aid
+    return G >= 4 && !(ve && atoi(ve) > 0);
+}
+
+static int choose_chunk(int B, int H_kv, int max_k, int G) {
     // NV_DECODE_CHUNK (multiple of 16) overrides the heuristic: a tuning aid
     const char* e = getenv("NV_DECODE_CHUNK");
     const int forced = e ? atoi(e) : 0;
@@ -575,7 +614,8 @@ static int choose_chunk(int B, int H_kv, int max_k) {
     // that one long sequence in a short batch cannot become a single-wave tail.
     const long long bh = (long long)B * H_kv;
     const char* te = getenv("NV_DECODE_TARGET_WAVES");  // tuning aid
-    const long long target = te && atoi(te) > 0 ? atoi(te) : NV_DEC_TARGET_WAVES;
+    const long long target = te && atoi(te) > 0 ? atoi(te)
+                             : (decode_uses_mfma(G) ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES);
     long long want = (target + bh - 1) / bh;
     if (want < 1) want = 1;
     long long chunk = (max_k + want - 1) / want;
@@ -595,7 +635,7 @@ static int num_splits(int max_k, int chunk) {
 extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k) {
     using namespace nv;
     if (B <= 0 || H_q <= 0 || H_kv <= 0 || D != kHeadDim || max_seqlen_k < 0) return 0;
-    const int chunk = choose_chunk(B, H_kv, max_seqlen_k);
+    const int chunk = choose_chunk(B, H_kv, max_seqlen_k, H_q / H_kv);
     const int ns = num_splits(max_seqlen_k, chunk);
     if (ns == 1) return 16;
     return (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
@@ -643,7 +683,7 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     p.max_blocks = max_blocks;
     p.H_kv = H_kv;
     p.block_size = block_size;
-    p.chunk = choose_chunk(B, H_kv, max_seqlen_k);
+    p.chunk = choose_chunk(B, H_kv, max_seqlen_k, H_q / H_kv);
     p.nsplit = num_splits(max_seqlen_k, p.chunk);
     p.num_blocks = num_blocks;
     p.q_stride_vec = q_stride_t / 8;
@@ -673,9 +713,7 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         if (aligned) NV_DEC_LAUNCH2(GG, true); \
         else NV_DEC_LAUNCH2(GG, false);      \
     } while (0)
-    // NV_DECODE_VALU=1 keeps G >= 4 on the all-VALU kernel: a tuning / comparison aid
-    const char* ve = getenv("NV_DECODE_VALU");
-    const bool use_mfma = G >= 4 && !(ve && atoi(ve) > 0);
+    const bool use_mfma = decode_uses_mfma(G);
     // one tile of prefetch measured faster than none on every G >= 4 shape tried
     const char* de = getenv("NV_DECODE_MFMA_DEPTH");  // tuning aid
     const bool mfma_deep = de ? atoi(de) > 0 : true;
@@ -708,8 +746,12 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     int rc = check_launch("nv_attn_decode_paged");
     if (rc != NV_OK) return rc;
     if (p.nsplit > 1) {
-        const unsigned mgrid = (unsigned)(((int64_t)B * H_q + 7) / 8);
-        hipLaunchKernelGGL(attn_decode_merge_kernel, dim3(mgrid), dim3(256), 0, st, p, H_q);
+        if (p.nsplit > 16) {
+            hipLaunchKernelGGL(attn_decode_merge_kernel<8>, dim3((unsigned)((int64_t)B * H_q)), dim3(256), 0, st, p, H_q);
+        } else {
+            const unsigned mgrid = (unsigned)(((int64_t)B * H_q + 7) / 8);
+            hipLaunchKernelGGL(attn_decode_merge_kernel<1>, dim3(mgrid), dim3(256), 0, st, p, H_q);
+        }
         rc = check_launch("nv_attn_decode_paged(merge)");
     }
     return rc;
