@@ -68,14 +68,87 @@ struct DecodeParams {
     float* part;  // [B, H_q, nsplit, kPartStride]
     int B, max_blocks, H_kv, block_size;
     int chunk, nsplit;
+    int G;  // query heads per kv head
     int64_t num_blocks;
     int64_t q_stride_vec, o_stride_vec;
     float scale_log2;
 };
 
+// Final state of one (sequence, query head, key chunk) held by 16 lanes (lane c: dims 8c..8c+7):
+// written as the bf16 output when the sequence is not split, else as an fp32 partial state.
+__device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq, int split, int tq, int c,
+                                            float m, float l, const float (&a)[8]) {
+    if (p.nsplit == 1) {
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        uint4 ov;
+        ov.x = pack_bf16(a[0] * inv, a[1] * inv);
+        ov.y = pack_bf16(a[2] * inv, a[3] * inv);
+        ov.z = pack_bf16(a[4] * inv, a[5] * inv);
+        ov.w = pack_bf16(a[6] * inv, a[7] * inv);
+        p.o[(int64_t)tq * p.o_stride_vec + (int64_t)hq * 16 + c] = ov;
+    } else {
+        const int H_q = p.H_kv * p.G;
+        float* dst = p.part + (((int64_t)b * H_q + hq) * p.nsplit + split) * kPartStride;
+        float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
+        d4[0] = make_float4(a[0], a[1], a[2], a[3]);
+        d4[1] = make_float4(a[4], a[5], a[6], a[7]);
+        if (c == 0) {
+            dst[kHeadDim] = m;
+            dst[kHeadDim + 1] = l;
+        }
+    }
+}
+
+// Workgroup-split form: the kDecWaves waves of a workgroup each streamed a quarter of one
+// (sequence, kv head, chunk); their states meet in LDS and wave w finishes heads w, w+4, ...
+// sm: [kDecWaves][G][kPartStride] floats.  Every wave of the workgroup must call this.
+template <int G>
+__device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm, int wave, int lane, int b, int h,
+                                               int split, int tq, const float (&m)[G], const float (&l)[G],
+                                               const float (&acc)[G][8]) {
+    const int c = lane & 15;
+    if (lane < 16) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float* dst = sm + (wave * G + g) * kPartStride;
+            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
+            d4[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+            d4[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
+            if (c == 0) {
+                dst[kHeadDim] = m[g];
+                dst[kHeadDim + 1] = l[g];
+            }
+        }
+    }
+    __syncthreads();
+    if (lane >= 16) return;
+    for (int g = wave; g < G; g += kDecWaves) {
+        float mm = kNegBig;
+#pragma unroll
+        for (int w = 0; w < kDecWaves; ++w) mm = fmaxf(mm, sm[(w * G + g) * kPartStride + kHeadDim]);
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float ls = 0.f;
+#pragma unroll
+        for (int w = 0; w < kDecWaves; ++w) {
+            const float* src = sm + (w * G + g) * kPartStride;
+            const float f = __builtin_amdgcn_exp2f(src[kHeadDim] - mm);
+            const float4 x = *reinterpret_cast<const float4*>(src + 8 * c);
+            const float4 y = *reinterpret_cast<const float4*>(src + 8 * c + 4);
+            a[0] += x.x * f; a[1] += x.y * f; a[2] += x.z * f; a[3] += x.w * f;
+            a[4] += y.x * f; a[5] += y.y * f; a[6] += y.z * f; a[7] += y.w * f;
+            ls += src[kHeadDim + 1] * f;
+        }
+        store_state(p, b, h * G + g, split, tq, c, mm, ls, a);
+    }
+}
+
 // kDepth = tiles (8 KiB per wave each) kept in flight ahead of the one being consumed.
-template <int G, bool ALIGNED, int kDepth>
+// WGS = false: every wave is its own work item.  WGS = true (launches with few (sequence, head)
+// pairs): the workgroup is one work item, its waves take a quarter of the chunk each and merge
+// through LDS, which replaces a 4-fold deeper global split (partial states and merge work / 4).
+template <int G, bool ALIGNED, int kDepth, bool WGS>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const DecodeParams p) {
+    __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kq = lane >> 4;  // which of the 4 keys of a load this lane holds
@@ -83,7 +156,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 
     // item -> (b, split, h), h fastest: the waves of a workgroup read neighbouring head
     // rows of the same tokens, i.e. whole contiguous cache rows.
-    const int item = blockIdx.x * kDecWaves + wave;
+    const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
     const int split = rest % p.nsplit;
@@ -96,10 +169,11 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
         if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // not a decode row
         tq = p.cu_q[b];
     }
-    const int k0 = split * p.chunk;
-    if (k0 >= n_k && !(split == 0)) return;
-    const int k1 = min(k0 + p.chunk, n_k);
-    const int H_q = p.H_kv * G;
+    const int kc0 = split * p.chunk;            // chunk of the work item
+    if (kc0 >= n_k && !(split == 0)) return;    // uniform over the workgroup when WGS
+    // this wave's keys [k0, k1): the whole chunk, or its wave-th quarter (a multiple of 16 keys)
+    const int k0 = WGS ? kc0 + wave * (p.chunk / kDecWaves) : kc0;
+    const int k1 = WGS ? min(min(kc0 + p.chunk, n_k), k0 + p.chunk / kDecWaves) : min(kc0 + p.chunk, n_k);
 
     uint4 qv[G];
 #pragma unroll
@@ -241,31 +315,13 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
         l[g] = la;
     }
 
-    if (kq != 0) return;
-    if (p.nsplit == 1) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float inv = l[g] > 0.f ? 1.0f / l[g] : 0.f;
-            uint4 ov;
-            ov.x = pack_bf16(acc[g][0] * inv, acc[g][1] * inv);
-            ov.y = pack_bf16(acc[g][2] * inv, acc[g][3] * inv);
-            ov.z = pack_bf16(acc[g][4] * inv, acc[g][5] * inv);
-            ov.w = pack_bf16(acc[g][6] * inv, acc[g][7] * inv);
-            p.o[(int64_t)tq * p.o_stride_vec + (int64_t)(h * G + g) * 16 + c] = ov;
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float* dst = p.part + (((int64_t)b * H_q + (h * G + g)) * p.nsplit + split) * kPartStride;
-            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
-            d4[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-            d4[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
-            if (c == 0) {
-                dst[kHeadDim] = m[g];
-                dst[kHeadDim + 1] = l[g];
-            }
-        }
+    if (WGS) {
+        wg_merge_store<G>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        return;
     }
+    if (kq != 0) return;
+#pragma unroll
+    for (int g = 0; g < G; ++g) store_state(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
 }
 
 // Variant for G >= 4 query heads per kv head.  The per-(key, head) lane reductions of the
@@ -282,10 +338,11 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 // common tile has no cross-lane maximum at all.
 constexpr float kDecRaise = 8.0f;
 
-template <int G, bool ALIGNED, int kDepth>
+template <int G, bool ALIGNED, int kDepth, bool WGS>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     static_assert(G == 4 || G == 8, "query heads per kv head");
     __shared__ __attribute__((aligned(16))) float xch_all[kDecWaves][16 * G + 16];
+    __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r4 = lane >> 4;  // S^T: key group; V layout: key of a 4-key load
@@ -293,7 +350,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     float* xp = xch_all[wave];       // [16 keys][G] probabilities of the current tile
     float* xa = xch_all[wave] + 16 * G;  // [16] per-head scalars (alpha, then m, l)
 
-    const int item = blockIdx.x * kDecWaves + wave;
+    const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
     const int split = rest % p.nsplit;
@@ -306,10 +363,11 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // not a decode row
         tq = p.cu_q[b];
     }
-    const int k0 = split * p.chunk;
-    if (k0 >= n_k && !(split == 0)) return;
-    const int k1 = min(k0 + p.chunk, n_k);
-    const int H_q = p.H_kv * G;
+    const int kc0 = split * p.chunk;            // chunk of the work item
+    if (kc0 >= n_k && !(split == 0)) return;    // uniform over the workgroup when WGS
+    // this wave's keys [k0, k1): the whole chunk, or its wave-th quarter (a multiple of 16 keys)
+    const int k0 = WGS ? kc0 + wave * (p.chunk / kDecWaves) : kc0;
+    const int k1 = WGS ? min(min(kc0 + p.chunk, n_k), k0 + p.chunk / kDecWaves) : min(kc0 + p.chunk, n_k);
 
     // B operand: lane (c, r4) holds Q[head c][dims 32 s + 8 r4 .. +7] for k-step s
     bf16x8 qf[4];
@@ -496,31 +554,13 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
             acc[g][j] = a;
         }
 
-    if (r4 != 0) return;
-    if (p.nsplit == 1) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float inv = l[g] > 0.f ? 1.0f / l[g] : 0.f;
-            uint4 ov;
-            ov.x = pack_bf16(acc[g][0] * inv, acc[g][1] * inv);
-            ov.y = pack_bf16(acc[g][2] * inv, acc[g][3] * inv);
-            ov.z = pack_bf16(acc[g][4] * inv, acc[g][5] * inv);
-            ov.w = pack_bf16(acc[g][6] * inv, acc[g][7] * inv);
-            p.o[(int64_t)tq * p.o_stride_vec + (int64_t)(h * G + g) * 16 + c] = ov;
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float* dst = p.part + (((int64_t)b * H_q + (h * G + g)) * p.nsplit + split) * kPartStride;
-            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
-            d4[0] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-            d4[1] = make_float4(acc[g][4], acc[g][5], acc[g][6], acc[g][7]);
-            if (c == 0) {
-                dst[kHeadDim] = m[g];
-                dst[kHeadDim + 1] = l[g];
-            }
-        }
+    if (WGS) {
+        wg_merge_store<G>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        return;
     }
+    if (r4 != 0) return;
+#pragma unroll
+    for (int g = 0; g < G; ++g) store_state(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
 }
 
 // Combine the per-chunk partial states of one (sequence, query head): 32 threads x 4 dims.
@@ -604,30 +644,48 @@ static bool decode_uses_mfma(int G) {
     return G >= 4 && !(ve && atoi(ve) > 0);
 }
 
-static int choose_chunk(int B, int H_kv, int max_k, int G) {
-    // NV_DECODE_CHUNK (multiple of 16) overrides the heuristic: a tuning aid
-    const char* e = getenv("NV_DECODE_CHUNK");
-    const int forced = e ? atoi(e) : 0;
-    if (forced > 0 && forced % 16 == 0) return forced;
-    // Fewest splits that still give the launch about NV_DEC_TARGET_WAVES waves; unsplit
-    // sequences are written directly (no partials, no merge launch).  Chunks are capped so
-    // that one long sequence in a short batch cannot become a single-wave tail.
+struct DecodePlan {
+    int chunk;   // keys per work item
+    int nsplit;  // work items per (sequence, kv head)
+    bool wgs;    // work item = workgroup (its waves split the chunk) instead of wave
+};
+
+static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
+    DecodePlan d;
     const long long bh = (long long)B * H_kv;
     const char* te = getenv("NV_DECODE_TARGET_WAVES");  // tuning aid
     const long long target = te && atoi(te) > 0 ? atoi(te)
                              : (decode_uses_mfma(G) ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES);
-    long long want = (target + bh - 1) / bh;
-    if (want < 1) want = 1;
-    long long chunk = (max_k + want - 1) / want;
-    chunk = (chunk + 63) / 64 * 64;
-    if (chunk < 64) chunk = 64;
-    if (chunk > 4096) chunk = 4096;
-    return (int)chunk;
-}
-
-static int num_splits(int max_k, int chunk) {
-    const int n = (max_k + chunk - 1) / chunk;
-    return n < 1 ? 1 : n;
+    // Few (sequence, kv head) pairs: a workgroup per work item, 4 waves on its chunk, so the
+    // launch reaches the target with a quarter of the partial states (often none at all).
+    // Not when the waves would stream >= 1024 keys each anyway and the cache row holds >= 4 kv
+    // heads: there the partials are cheap, and four waves on neighbouring heads of the same
+    // tokens (1 KiB contiguous per token) beat four waves on distant tokens (measured 6.2 vs
+    // 5.7 TB/s at 8 sequences x 32 k keys).
+    const long long wave_keys = max_k / ((target + bh - 1) / bh > 0 ? (target + bh - 1) / bh : 1);
+    const char* we = getenv("NV_DECODE_WGS");  // 0 / 1 forces the form: a tuning aid
+    d.wgs = we ? atoi(we) > 0 : (bh * 2 <= target && (H_kv <= 2 || wave_keys < 1024));
+    // NV_DECODE_CHUNK (multiple of 64) overrides the heuristic: a tuning aid
+    const char* e = getenv("NV_DECODE_CHUNK");
+    const int forced = e ? atoi(e) : 0;
+    if (forced > 0 && forced % 64 == 0) {
+        d.chunk = forced;
+    } else {
+        // Fewest splits that still give the launch about `target` waves; unsplit sequences are
+        // written directly (no partials, no merge launch).  Chunks are capped so that one long
+        // sequence in a short batch cannot become a single-item tail.
+        const long long want_items = d.wgs ? target / kDecWaves : target;
+        long long want = (want_items + bh - 1) / bh;
+        if (want < 1) want = 1;
+        long long chunk = (max_k + want - 1) / want;
+        chunk = (chunk + 63) / 64 * 64;
+        const long long lo = d.wgs ? 64 * kDecWaves : 64, hi = d.wgs ? 4096 * kDecWaves : 4096;
+        chunk = chunk < lo ? lo : (chunk > hi ? hi : chunk);
+        d.chunk = (int)chunk;
+    }
+    const int n = (max_k + d.chunk - 1) / d.chunk;
+    d.nsplit = n < 1 ? 1 : n;
+    return d;
 }
 
 }  // namespace nv
@@ -635,8 +693,7 @@ static int num_splits(int max_k, int chunk) {
 extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k) {
     using namespace nv;
     if (B <= 0 || H_q <= 0 || H_kv <= 0 || D != kHeadDim || max_seqlen_k < 0) return 0;
-    const int chunk = choose_chunk(B, H_kv, max_seqlen_k, H_q / H_kv);
-    const int ns = num_splits(max_seqlen_k, chunk);
+    const int ns = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv).nsplit;
     if (ns == 1) return 16;
     return (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
 }
@@ -683,8 +740,10 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     p.max_blocks = max_blocks;
     p.H_kv = H_kv;
     p.block_size = block_size;
-    p.chunk = choose_chunk(B, H_kv, max_seqlen_k, H_q / H_kv);
-    p.nsplit = num_splits(max_seqlen_k, p.chunk);
+    const DecodePlan plan = plan_decode(B, H_kv, max_seqlen_k, G);
+    p.chunk = plan.chunk;
+    p.nsplit = plan.nsplit;
+    p.G = G;
     p.num_blocks = num_blocks;
     p.q_stride_vec = q_stride_t / 8;
     p.o_stride_vec = o_stride_t / 8;
@@ -696,17 +755,20 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
                    (long long)workspace_bytes, (long long)need);
     }
     const int64_t items = (int64_t)B * p.nsplit * H_kv;
-    const unsigned grid = (unsigned)((items + kDecWaves - 1) / kDecWaves);
+    const bool wgs = plan.wgs;
+    NV_REQUIRE(items < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
+    const unsigned grid = wgs ? (unsigned)items : (unsigned)((items + kDecWaves - 1) / kDecWaves);
     hipStream_t st = (hipStream_t)stream;
-    const bool aligned = block_size % 16 == 0 && p.chunk % 16 == 0;
+    const bool aligned = block_size % 16 == 0 && p.chunk % 64 == 0;
     // Prefetch depth: one tile ahead hides HBM latency when each wave streams a long chunk
     // and waves are scarce; with many resident waves (or G = 8, where registers are the
     // limit) thread-level parallelism already covers it and the leaner kernel is faster.
     const bool lean = G >= 8 || (p.nsplit == 1 && items >= NV_DEC_TARGET_WAVES);
 #define NV_DEC_LAUNCH2(GG, AL)                                                                      \
     do {                                                                                            \
-        if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 0>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
-        else hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);      \
+        if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);       \
+        else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 0, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
     } while (0)
 #define NV_DEC_LAUNCH(GG)                    \
     do {                                     \
@@ -719,8 +781,9 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     const bool mfma_deep = de ? atoi(de) > 0 : true;
 #define NV_DEC_LAUNCH_M2(GG, AL)                                                                    \
     do {                                                                                            \
-        if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
-        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 0>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
+        if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \
+        else if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 0, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);               \
     } while (0)
 #define NV_DEC_LAUNCH_M(GG)                      \
     do {                                         \

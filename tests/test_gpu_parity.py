@@ -315,6 +315,21 @@ def test_decode_monotone_scores(hip, H_q, H_kv, direction):
     _attn_check(_run_attention(ops, pd, "decode"), ref, f"decode-{direction}")
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+@pytest.mark.parametrize("H_q,H_kv,bs", [(16, 8, 256), (32, 8, 256), (8, 1, 256), (4, 4, 48)])
+def test_decode_both_work_item_forms(hip, monkeypatch, form, H_q, H_kv, bs):
+    """Work item = wave (0) or workgroup whose four waves split the chunk and merge in LDS (1), each
+    forced, with and without a global split (long and short contexts, empty quarters, 48-token blocks)."""
+    _, ops = hip
+    n_ks = [1, 17, 63, 64, 65, 255, 700, 3000, 5000]
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 2
+    p = make_paged_problem(H_q + bs, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    monkeypatch.setenv("NV_DECODE_WGS", form)
+    _attn_check(_run_attention(ops, to_dev(p), "decode"), ref, f"decode-form{form}")
+
+
 def test_decode_zero_length_sequence_gives_zeros(hip):
     _, ops = hip
     p = make_paged_problem(9, [1, 1], [0, 40], 16, 8, 256, 3)

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--ctx-hi", type=int, default=768)
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
-    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice)")
+    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
@@ -50,7 +50,10 @@ def main():
           for mode in args.modes.split(","):
             os.environ.pop("NV_DECODE_VALU", None)
             os.environ.pop("NV_DECODE_MFMA_DEPTH", None)
-            if mode == "valu":
+            os.environ.pop("NV_DECODE_WGS", None)
+            if mode in ("wgs0", "wgs1"):
+                os.environ["NV_DECODE_WGS"] = mode[3]
+            elif mode == "valu":
                 os.environ["NV_DECODE_VALU"] = "1"
             elif mode.startswith("mfma"):
                 os.environ["NV_DECODE_MFMA_DEPTH"] = mode[4:]
@@ -80,7 +83,7 @@ def main():
         med, best = statistics.median(ts), min(ts)
         print(f"{name:>16s} chunk={chunk:4d}  median {med*1e3:8.2f} us  {nbytes/med/1e6:7.1f} GB/s   "
               f"best {best*1e3:8.2f} us {nbytes/best/1e6:7.1f} GB/s")
-    for k in ("NV_DECODE_CHUNK", "NV_DECODE_TARGET_WAVES", "NV_DECODE_VALU", "NV_DECODE_MFMA_DEPTH"):
+    for k in ("NV_DECODE_CHUNK", "NV_DECODE_TARGET_WAVES", "NV_DECODE_VALU", "NV_DECODE_MFMA_DEPTH", "NV_DECODE_WGS"):
         os.environ.pop(k, None)
 
 
