@@ -20,8 +20,35 @@ from ..utils.cache_context import CacheContext, set_context
 from .sequence import Sequence
 
 
-def prepare_inputs(seqs: list[Sequence], block_size: int) -> dict:
+def _prepare_decode_inputs(seqs: list[Sequence], block_size: int) -> dict:
+    """prepare_inputs for a step in which every sequence has exactly one (decode) token: the same
+    integers, built from flat python lists and whole-array numpy operations."""
+    B = len(seqs)
+    width = max(len(s.block_table) for s in seqs)
+    flat: list[int] = []
+    pad = [-1] * width
+    for s in seqs:
+        bt = s.block_table
+        flat.extend(bt)
+        if len(bt) < width:
+            flat.extend(pad[len(bt):])
+    tables = np.array(flat, dtype=np.int32).reshape(B, width)
+    start = np.array([s.num_computed_tokens for s in seqs], dtype=np.int64)
+    input_ids = np.array([s.output_tokens[-1] for s in seqs], dtype=np.int64)
+    positions = np.array([len(s) - 1 for s in seqs], dtype=np.int64)
+    slots = tables[np.arange(B), start // block_size].astype(np.int64) * block_size + start % block_size
+    cu_q = np.arange(B + 1, dtype=np.int32)
+    cu_k = np.zeros(B + 1, dtype=np.int32)
+    np.cumsum(start + 1, out=cu_k[1:])
+    return dict(input_ids=input_ids, positions=positions, slot_mapping=slots.astype(np.int32), cu_seqlens_q=cu_q,
+                cu_seqlens_k=cu_k, max_seqlen_q=1, max_seqlen_k=int(start.max()) + 1, block_tables=tables,
+                num_decode_seqs=B)
+
+
+def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool = True) -> dict:
     """Pure host part: python ints / numpy arrays for one step (see module docstring)."""
+    if decode_fast_path and all(s.num_scheduled_tokens == 1 and not s.is_prefill for s in seqs):
+        return _prepare_decode_inputs(seqs, block_size)
     ids, pos, slots = [], [], []
     n_q = np.empty(len(seqs), dtype=np.int64)
     n_k = np.empty(len(seqs), dtype=np.int64)
@@ -61,12 +88,30 @@ class _DecodeGraph:
     def __init__(self, runner: "ModelRunner", batch: int, width: int):
         dev = runner.device
         self.batch, self.width = batch, width
-        self.input_ids = torch.zeros(batch, dtype=torch.int64, device=dev)
-        self.positions = torch.zeros(batch, dtype=torch.int64, device=dev)
-        self.slot_mapping = torch.full((batch,), -1, dtype=torch.int32, device=dev)
+        # All per-step metadata lives in ONE device buffer with a pinned host mirror, so a step is one
+        # host-to-device copy: [input_ids i64 x B | positions i64 x B | slot_mapping i32 x B |
+        # cu_seqlens_k i32 x (B+1) | block_tables i32 x B*W], every section 8-byte aligned.
+        def sec(n_items, itemsize, off):
+            nbytes = -(-n_items * itemsize // 8) * 8
+            return off, off + n_items * itemsize, off + nbytes
+        o_ids = sec(batch, 8, 0)
+        o_pos = sec(batch, 8, o_ids[2])
+        o_slot = sec(batch, 4, o_pos[2])
+        o_cuk = sec(batch + 1, 4, o_slot[2])
+        o_bt = sec(batch * width, 4, o_cuk[2])
+        self._dev_buf = torch.zeros(o_bt[2], dtype=torch.uint8, device=dev)
+        self._host_buf = torch.zeros(o_bt[2], dtype=torch.uint8, pin_memory=dev.type == "cuda")
+
+        def views(buf):
+            return (buf[o_ids[0]:o_ids[1]].view(torch.int64), buf[o_pos[0]:o_pos[1]].view(torch.int64),
+                    buf[o_slot[0]:o_slot[1]].view(torch.int32), buf[o_cuk[0]:o_cuk[1]].view(torch.int32),
+                    buf[o_bt[0]:o_bt[1]].view(torch.int32).view(batch, width))
+        self.input_ids, self.positions, self.slot_mapping, self.cu_seqlens_k, self.block_tables = views(self._dev_buf)
+        self._h = [t.numpy() for t in views(self._host_buf)]
+        self._h[2].fill(-1)
+        self._h[4].fill(-1)
+        self._dev_buf.copy_(self._host_buf)
         self.cu_seqlens_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
-        self.cu_seqlens_k = torch.zeros(batch + 1, dtype=torch.int32, device=dev)
-        self.block_tables = torch.full((batch, width), -1, dtype=torch.int32, device=dev)
         self.ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self.slot_mapping,
                                 cu_seqlens_q=self.cu_seqlens_q, cu_seqlens_k=self.cu_seqlens_k, max_seqlen_q=1,
                                 max_seqlen_k=width * runner.block_size, block_tables=self.block_tables,
@@ -83,24 +128,20 @@ class _DecodeGraph:
         with torch.cuda.graph(self.graph):
             self.logits = runner.model(self.input_ids, self.positions)
 
-    def replay(self, m: dict, to_device) -> torch.Tensor:
+    def replay(self, m: dict) -> torch.Tensor:
         n = len(m["input_ids"])
-        pad = self.batch - n
+        h_ids, h_pos, h_slot, h_cuk, h_bt = self._h
+        h_ids[:n] = m["input_ids"]
+        h_pos[:n] = m["positions"]
+        h_slot[:n] = m["slot_mapping"]
+        h_slot[n:] = -1                            # padded rows: slot -1 (skipped), no keys, token 0
+        h_cuk[:n + 1] = m["cu_seqlens_k"]
+        h_cuk[n + 1:] = m["cu_seqlens_k"][-1]
         bt = m["block_tables"]
-        if pad or bt.shape[1] < self.width:
-            full = np.full((self.batch, self.width), -1, dtype=np.int32)
-            full[:n, :bt.shape[1]] = bt
-            bt = full
-        cu_k = m["cu_seqlens_k"]
-        if pad:                                   # padded rows: no keys, slot -1 (skipped), token 0
-            cu_k = np.concatenate([cu_k, np.full(pad, cu_k[-1], dtype=np.int32)])
-        self.input_ids[:n].copy_(to_device(m["input_ids"]), non_blocking=True)
-        self.positions[:n].copy_(to_device(m["positions"]), non_blocking=True)
-        self.slot_mapping[:n].copy_(to_device(m["slot_mapping"]), non_blocking=True)
-        if pad:
-            self.slot_mapping[n:].fill_(-1)
-        self.cu_seqlens_k.copy_(to_device(cu_k), non_blocking=True)
-        self.block_tables.copy_(to_device(bt), non_blocking=True)
+        h_bt[:n, :bt.shape[1]] = bt
+        h_bt[:n, bt.shape[1]:] = -1
+        h_bt[n:] = -1
+        self._dev_buf.copy_(self._host_buf, non_blocking=True)
         self.graph.replay()
         return self.logits[:n]
 
@@ -175,12 +216,17 @@ class ModelRunner:
             m = prepare_inputs(seqs, self.block_size)
             batch = -(-len(seqs) // 16) * 16
             width = 1 << max(0, int(m["block_tables"].shape[1] - 1).bit_length())     # next power of two
-            key = (batch, width)
-            if key not in self._graphs:
-                self._graphs[key] = _DecodeGraph(self, batch, width)
-            g = self._graphs[key]
+            g = self._graphs.get((batch, width))
+            if g is None:
+                # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
+                # costs two eager forwards): only capture when nothing within 25 % exists
+                fits = [k for k in self._graphs if k[1] == width and batch <= k[0] <= batch + max(16, batch // 4)]
+                if fits:
+                    g = self._graphs[min(fits)]
+                else:
+                    g = self._graphs[(batch, width)] = _DecodeGraph(self, batch, width)
             set_context(g.ctx)
-            logits = g.replay(m, self._to_device)
+            logits = g.replay(m)
         else:
             input_ids, positions, m = self.set_step_context(seqs)
             last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)

@@ -144,6 +144,29 @@ def test_prepare_inputs_matches_reference_restatement():
     assert mine["num_decode_seqs"] == sum(s.num_scheduled_tokens == 1 for s in seqs)
 
 
+def test_prepare_inputs_decode_fast_path_matches_general_path():
+    """A decode-only step is built by a vectorised path: same integers as the general path and as the
+    restatement of the reference, ragged block-table widths included."""
+    rng = np.random.default_rng(3)
+    bs = 16
+    seqs, nxt = [], 0
+    for _ in range(37):
+        s = Sequence(rng.integers(0, 1000, size=int(rng.integers(1, 70))).tolist(), SamplingParams(0.0, 8))
+        s.output_tokens = rng.integers(0, 1000, size=int(rng.integers(1, 40))).tolist()
+        s.num_computed_tokens = len(s) - 1
+        s.num_scheduled_tokens = 1
+        nb = -(-len(s) // bs)
+        s.block_table = rng.permutation(np.arange(nxt, nxt + nb)).tolist()
+        nxt += nb
+        seqs.append(s)
+    fast, slow = prepare_inputs(seqs, bs), prepare_inputs(seqs, bs, decode_fast_path=False)
+    ref = ref_metadata.prepare_inputs_ref(seqs, bs)
+    for key in ("input_ids", "positions", "slot_mapping", "cu_seqlens_q", "cu_seqlens_k", "block_tables"):
+        assert fast[key].dtype == slow[key].dtype and fast[key].tolist() == slow[key].tolist() == ref[key], key
+    for key in ("max_seqlen_q", "max_seqlen_k", "num_decode_seqs"):
+        assert fast[key] == slow[key], key
+
+
 def test_sampler_greedy_and_temperature():
     logits = torch.tensor([[0.0, 5.0, 1.0], [9.0, 0.0, 0.0]])
     assert sample(logits, [0.0, 0.0]).tolist() == [1, 0]
