@@ -114,6 +114,7 @@ class BlockManager:
         bs = self.block_size
         table = self._tables[seq.id]
         done = self._hashed[seq.id]
+        num_tokens_in_cache = min(num_tokens_in_cache, len(seq) - seq.num_pending)   # only known token values
         full = min(num_tokens_in_cache // bs, len(table))
         if full <= done:
             return

@@ -45,13 +45,19 @@ class LLMEngine:
     def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
                  max_num_batched_tokens: int = 4000, long_prefill_token_threshold: int = 512,
                  gpu_memory_utilization: float = 0.9, device="cuda", eos: int | None = None,
-                 max_num_seqs: int | None = None, tokenizer=None, use_graphs: bool = False):
+                 max_num_seqs: int | None = None, tokenizer=None, use_graphs: bool = False,
+                 pipelined_decode: bool = False):
+        """pipelined_decode: decode-only steps are enqueued one ahead of the host: step t+1 is scheduled
+        and launched (its input tokens are taken on the device) while step t runs, and the values of
+        step t are read afterwards.  Tokens are identical to the synchronous loop; a sequence that
+        samples EOS costs one surplus row in the step that was already in flight."""
         self.runner = ModelRunner(model, cfg, block_size, num_kvcache_blocks, gpu_memory_utilization, device,
                                   use_graphs=use_graphs)
         self.scheduler = Scheduler(self.runner.num_kvcache_blocks, block_size, max_num_batched_tokens,
                                    long_prefill_token_threshold, eos if eos is not None else cfg.eos_token_id,
                                    max_num_seqs)
         self.tokenizer = tokenizer
+        self.pipelined_decode = pipelined_decode
 
     def add_request(self, prompt, sampling_params: SamplingParams | None = None) -> Sequence:
         if isinstance(prompt, str):
@@ -88,18 +94,39 @@ class LLMEngine:
         metrics = GenerationMetrics(num_prompt_tokens=sum(len(s.prompt_tokens) for s in seqs))
         cuda = self.runner.device.type == "cuda"
         t_start = time.perf_counter()
-        while not self.is_finished():
+        inflight = None                      # pipelined decode: (sequences, handle) of the step on the device
+        while not self.is_finished() or inflight is not None:
             t0 = time.perf_counter()
-            scheduled, tokens, _, decode_only = self.step()
+            batch = self.scheduler.schedule()[0] if not self.is_finished() else []
+            if self.pipelined_decode and batch and all(not s.is_prefill and s.num_scheduled_tokens == 1 for s in batch):
+                handle = self.runner.launch_decode(batch, inflight[1] if inflight else None)
+                if inflight is not None:     # read step t while step t+1 runs
+                    self.scheduler.resolve_pending(inflight[0], self.runner.fetch_tokens(inflight[1]))
+                self.scheduler.advance_pending(batch)
+                inflight = (batch, handle)
+                metrics.step_times.append((time.perf_counter() - t0, len(batch), True))
+                continue
+            if inflight is not None:         # a step with prompt rows needs the token values on the host
+                self.scheduler.resolve_pending(inflight[0], self.runner.fetch_tokens(inflight[1]))
+                inflight = None
+                kept = [s for s in batch if not s.is_finished]      # minus sequences that just hit EOS
+                for s in batch:
+                    if s.is_finished:
+                        s.num_scheduled_tokens = 0
+                batch = kept
+            if not batch:
+                continue
+            decode_only = all(not s.is_prefill for s in batch)
+            tokens = self.runner.run(batch)
+            self.scheduler.update_from_output(batch, tokens)
             if cuda:
                 torch.cuda.synchronize(self.runner.device)
             now = time.perf_counter()
-            n_gen = sum(t is not None for t in tokens)
-            metrics.step_times.append((now - t0, n_gen, decode_only))
-            for s, t in zip(scheduled, tokens):
+            metrics.step_times.append((now - t0, sum(t is not None for t in tokens), decode_only))
+            for s, t in zip(batch, tokens):
                 if t is not None and len(s.output_tokens) == 1:
                     metrics.first_token_time[s.id] = now - t_start
-            metrics.num_generated_tokens += n_gen
+        metrics.num_generated_tokens = sum(len(s.output_tokens) for s in seqs)
         metrics.wall_time = time.perf_counter() - t_start
         outs = []
         for s in seqs:

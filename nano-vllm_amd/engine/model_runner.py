@@ -99,15 +99,19 @@ class _DecodeGraph:
         o_slot = sec(batch, 4, o_pos[2])
         o_cuk = sec(batch + 1, 4, o_slot[2])
         o_bt = sec(batch * width, 4, o_cuk[2])
-        self._dev_buf = torch.zeros(o_bt[2], dtype=torch.uint8, device=dev)
-        self._host_buf = torch.zeros(o_bt[2], dtype=torch.uint8, pin_memory=dev.type == "cuda")
+        o_src = sec(batch, 8, o_bt[2])      # pipelined decode: row of the previous step's tokens, or -1
+        self._dev_buf = torch.zeros(o_src[2], dtype=torch.uint8, device=dev)
+        self._host_buf = torch.zeros(o_src[2], dtype=torch.uint8, pin_memory=dev.type == "cuda")
 
         def views(buf):
             return (buf[o_ids[0]:o_ids[1]].view(torch.int64), buf[o_pos[0]:o_pos[1]].view(torch.int64),
                     buf[o_slot[0]:o_slot[1]].view(torch.int32), buf[o_cuk[0]:o_cuk[1]].view(torch.int32),
-                    buf[o_bt[0]:o_bt[1]].view(torch.int32).view(batch, width))
-        self.input_ids, self.positions, self.slot_mapping, self.cu_seqlens_k, self.block_tables = views(self._dev_buf)
+                    buf[o_bt[0]:o_bt[1]].view(torch.int32).view(batch, width),
+                    buf[o_src[0]:o_src[1]].view(torch.int64))
+        (self.input_ids, self.positions, self.slot_mapping, self.cu_seqlens_k, self.block_tables,
+         self.src_rows) = views(self._dev_buf)
         self._h = [t.numpy() for t in views(self._host_buf)]
+        self._h[5].fill(-1)
         self._h[2].fill(-1)
         self._h[4].fill(-1)
         self._dev_buf.copy_(self._host_buf)
@@ -128,9 +132,13 @@ class _DecodeGraph:
         with torch.cuda.graph(self.graph):
             self.logits = runner.model(self.input_ids, self.positions)
 
-    def replay(self, m: dict) -> torch.Tensor:
+    def replay(self, m: dict, src_rows: np.ndarray | None = None, prev_tokens: torch.Tensor | None = None) -> torch.Tensor:
+        """src_rows / prev_tokens (pipelined decode): row i takes its input token from
+        prev_tokens[src_rows[i]] (still on the device) where src_rows[i] >= 0."""
         n = len(m["input_ids"])
-        h_ids, h_pos, h_slot, h_cuk, h_bt = self._h
+        h_ids, h_pos, h_slot, h_cuk, h_bt, h_src = self._h
+        if src_rows is not None:
+            h_src[:n] = src_rows
         h_ids[:n] = m["input_ids"]
         h_pos[:n] = m["positions"]
         h_slot[:n] = m["slot_mapping"]
@@ -142,6 +150,9 @@ class _DecodeGraph:
         h_bt[:n, bt.shape[1]:] = -1
         h_bt[n:] = -1
         self._dev_buf.copy_(self._host_buf, non_blocking=True)
+        if src_rows is not None:
+            src = self.src_rows[:n]
+            self.input_ids[:n] = torch.where(src >= 0, prev_tokens[src.clamp(min=0)], self.input_ids[:n])
         self.graph.replay()
         return self.logits[:n]
 
@@ -198,8 +209,9 @@ class ModelRunner:
             return t.pin_memory().to(self.device, non_blocking=True)
         return t
 
-    def set_step_context(self, seqs: list[Sequence]):
-        m = prepare_inputs(seqs, self.block_size)
+    def set_step_context(self, seqs: list[Sequence], m: dict | None = None):
+        if m is None:
+            m = prepare_inputs(seqs, self.block_size)
         ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self._to_device(m["slot_mapping"]),
                            cu_seqlens_q=self._to_device(m["cu_seqlens_q"]),
                            cu_seqlens_k=self._to_device(m["cu_seqlens_k"]), max_seqlen_q=m["max_seqlen_q"],
@@ -208,23 +220,71 @@ class ModelRunner:
         set_context(ctx)
         return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
 
+    def _graph_for(self, n_seqs: int, table_width: int) -> _DecodeGraph:
+        batch = -(-n_seqs // 16) * 16
+        width = 1 << max(0, int(table_width - 1).bit_length())     # next power of two
+        g = self._graphs.get((batch, width))
+        if g is None:
+            # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
+            # costs two eager forwards): only capture when nothing within 25 % exists
+            fits = [k for k in self._graphs if k[1] == width and batch <= k[0] <= batch + max(16, batch // 4)]
+            if fits:
+                g = self._graphs[min(fits)]
+            else:
+                g = self._graphs[(batch, width)] = _DecodeGraph(self, batch, width)
+        return g
+
+    @torch.inference_mode()
+    def launch_decode(self, seqs: list[Sequence], prev: dict | None) -> dict:
+        """Pipelined decode: enqueue a decode-only step without waiting for the previous step's token
+        values.  Sequences whose last output token is still PENDING take it on the device from `prev`
+        (the handle this method returned for the previous step).  Returns a handle for fetch_tokens()."""
+        m = prepare_inputs(seqs, self.block_size)
+        src = np.full(len(seqs), -1, dtype=np.int64)
+        if prev is not None:
+            rows = prev["rows"]
+            for i, s in enumerate(seqs):
+                if s.num_pending:
+                    src[i] = rows[s.id]
+        assert not any(s.num_pending and src[i] < 0 for i, s in enumerate(seqs)), "pending token without a source"
+        ids = m["input_ids"]
+        ids[ids < 0] = 0                                    # placeholders never reach the embedding
+        prev_tokens = prev["tokens"] if prev is not None else None
+        if self.use_graphs:
+            g = self._graph_for(len(seqs), m["block_tables"].shape[1])
+            set_context(g.ctx)
+            logits = g.replay(m, src if prev is not None else None, prev_tokens)
+        else:
+            input_ids, positions, m = self.set_step_context(seqs, m)
+            if prev is not None:
+                src_d = self._to_device(src)
+                input_ids = torch.where(src_d >= 0, prev_tokens[src_d.clamp(min=0)], input_ids)
+            logits = self.model(input_ids, positions)
+        tokens = sample(logits, [s.sampling_params.temperature for s in seqs])
+        handle = {"rows": {s.id: i for i, s in enumerate(seqs)}, "tokens": tokens, "event": None}
+        if self.device.type == "cuda":
+            host = torch.empty(len(seqs), dtype=torch.int64, pin_memory=True)
+            host.copy_(tokens, non_blocking=True)
+            handle["host"] = host
+            handle["event"] = torch.cuda.Event()
+            handle["event"].record()
+        else:
+            handle["host"] = tokens
+        return handle
+
+    @staticmethod
+    def fetch_tokens(handle: dict) -> list[int]:
+        if handle["event"] is not None:
+            handle["event"].synchronize()
+        return handle["host"].tolist()
+
     @torch.inference_mode()
     def run(self, seqs: list[Sequence]) -> list[int | None]:
         """Forward the scheduled tokens; returns one sampled token per sequence, or None while a
         sequence's prompt is still being chunked (model_runner.py:214-240)."""
         if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
             m = prepare_inputs(seqs, self.block_size)
-            batch = -(-len(seqs) // 16) * 16
-            width = 1 << max(0, int(m["block_tables"].shape[1] - 1).bit_length())     # next power of two
-            g = self._graphs.get((batch, width))
-            if g is None:
-                # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
-                # costs two eager forwards): only capture when nothing within 25 % exists
-                fits = [k for k in self._graphs if k[1] == width and batch <= k[0] <= batch + max(16, batch // 4)]
-                if fits:
-                    g = self._graphs[min(fits)]
-                else:
-                    g = self._graphs[(batch, width)] = _DecodeGraph(self, batch, width)
+            g = self._graph_for(len(seqs), m["block_tables"].shape[1])
             set_context(g.ctx)
             logits = g.replay(m)
         else:

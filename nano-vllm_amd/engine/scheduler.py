@@ -13,7 +13,7 @@ from __future__ import annotations
 from collections import deque
 
 from .block_manager import BlockManager
-from .sequence import Sequence, SequenceStatus
+from .sequence import PENDING, Sequence, SequenceStatus
 
 
 class Scheduler:
@@ -84,6 +84,51 @@ class Scheduler:
             admitted += 1
         return scheduled, admitted > 0
 
+    def _retire(self, finished: list[Sequence]) -> None:
+        for seq in finished:
+            self.block_manager.free_sequence(seq.id)
+            seq.block_table = []
+        self.running = deque(s for s in self.running if not s.is_finished)
+
+    def advance_pending(self, seqs: list[Sequence]) -> list[Sequence]:
+        """Pipelined decode: account a launched decode-only step before its tokens are known.  Every
+        sequence gets a PENDING output token; those that reach max_tokens finish now (their last value
+        arrives with resolve_pending).  Returns the sequences that finished."""
+        finished = []
+        for seq in seqs:
+            seq.num_computed_tokens += seq.num_scheduled_tokens
+            seq.num_scheduled_tokens = 0
+            seq.add_token(PENDING)
+            seq.num_pending += 1
+            if len(seq.output_tokens) >= seq.sampling_params.max_tokens:
+                seq.status = SequenceStatus.FINISHED
+                finished.append(seq)
+        if finished:
+            self._retire(finished)
+        return finished
+
+    def resolve_pending(self, seqs: list[Sequence], token_ids: list[int]) -> list[Sequence]:
+        """Fill in the values of a step accounted by advance_pending.  A sequence that turns out to
+        have sampled EOS finishes here; the token of a step that was launched for it in the meantime
+        is dropped when that step resolves.  Returns the sequences that finished on EOS."""
+        finished = []
+        for seq, token_id in zip(seqs, token_ids):
+            if seq.stopped_early:                 # launched before its EOS was seen: discard
+                if seq.num_pending:
+                    seq.output_tokens.pop()
+                    seq.num_pending -= 1
+                continue
+            assert seq.num_pending >= 1, "resolve_pending without a pending token"
+            seq.output_tokens[len(seq.output_tokens) - seq.num_pending] = token_id
+            seq.num_pending -= 1
+            if token_id == self.eos and not seq.is_finished:
+                seq.status = SequenceStatus.FINISHED
+                seq.stopped_early = True
+                finished.append(seq)
+        if finished:
+            self._retire(finished)
+        return finished
+
     def update_from_output(self, seqs: list[Sequence], token_ids: list[int | None]) -> list[Sequence]:
         """Account the step: advance computed counts, append sampled tokens (None = prompt not yet
         complete), finish and free.  Returns the sequences that finished."""
@@ -97,8 +142,5 @@ class Scheduler:
                     seq.status = SequenceStatus.FINISHED
                     finished.append(seq)
         if finished:
-            for seq in finished:
-                self.block_manager.free_sequence(seq.id)
-                seq.block_table = []
-            self.running = deque(s for s in self.running if not s.is_finished)
+            self._retire(finished)
         return finished

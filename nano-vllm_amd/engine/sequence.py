@@ -21,6 +21,9 @@ class SequenceStatus(Enum):
     FINISHED = "finished"
 
 
+PENDING = -1   # placeholder for a sampled token whose value is still on the device
+
+
 class Sequence:
     _ids = count()
 
@@ -33,6 +36,8 @@ class Sequence:
         self.num_cached_tokens = 0        # of those, prompt tokens found in the prefix cache at admission
         self.num_scheduled_tokens = 0     # tokens to process in the coming step
         self.block_table: list[int] = []  # physical block ids, logical order
+        self.num_pending = 0              # trailing output tokens that are still PENDING (0 or 1)
+        self.stopped_early = False        # finished on EOS while a later step was already in flight
         self.sampling_params = sampling_params or SamplingParams()
 
     def __len__(self) -> int:

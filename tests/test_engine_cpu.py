@@ -176,7 +176,7 @@ def test_sampler_greedy_and_temperature():
     assert set(out[1::2].tolist()) <= {0, 1, 2}
 
 
-def _tiny_engine(block_size, num_blocks, seed=0, chunk=32):
+def _tiny_engine(block_size, num_blocks, seed=0, chunk=32, **kw):
     cfg = ModelConfig(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
                       num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=1024)
     torch.manual_seed(seed)
@@ -184,7 +184,7 @@ def _tiny_engine(block_size, num_blocks, seed=0, chunk=32):
     for p in model.parameters():
         torch.nn.init.normal_(p, 0.0, 0.05)
     return LLMEngine(model, cfg, block_size=block_size, num_kvcache_blocks=num_blocks, max_num_batched_tokens=64,
-                     long_prefill_token_threshold=chunk, device="cpu", eos=-1), cfg
+                     long_prefill_token_threshold=chunk, device="cpu", **({"eos": -1} | kw)), cfg
 
 
 def test_engine_end_to_end_on_cpu_with_oracle_layers():
@@ -203,6 +203,30 @@ def test_engine_end_to_end_on_cpu_with_oracle_layers():
         solo.scheduler.max_scheduled_tokens = 4000
         ref_out, _ = solo.generate([p], SamplingParams(0.0, 6))
         assert ref_out[0]["token_ids"] == o["token_ids"]
+
+
+def test_pipelined_decode_gives_the_same_tokens():
+    """Decode steps launched one ahead of the host (token values read a step late) must produce exactly
+    the synchronous loop's outputs: staggered max_tokens, requests arriving with different prompt
+    lengths (mixed steps drain the pipeline), and an EOS that is discovered one step late."""
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (16, 13, 70, 40, 33)]
+    params = [SamplingParams(0.0, n) for n in (9, 3, 12, 1, 7)]
+    ref_eng, _ = _tiny_engine(16, 64)
+    ref, _ = ref_eng.generate(prompts, params)
+    eng, _ = _tiny_engine(16, 64, pipelined_decode=True)
+    out, m = eng.generate(prompts, params)
+    assert [o["token_ids"] for o in out] == [o["token_ids"] for o in ref]
+    assert eng.scheduler.block_manager.num_free_blocks == 64 and m.num_generated_tokens == 9 + 3 + 12 + 1 + 7
+    # EOS: pick a token the third request emits mid-way; both loops must stop that request there
+    eos = ref[2]["token_ids"][5]
+    ref_eos, _ = _tiny_engine(16, 64, eos=eos)[0].generate(prompts, params)
+    eng2, _ = _tiny_engine(16, 64, eos=eos, pipelined_decode=True)
+    out_eos, _ = eng2.generate(prompts, params)
+    assert [o["token_ids"] for o in out_eos] == [o["token_ids"] for o in ref_eos]
+    assert len(ref_eos[2]["token_ids"]) <= 6 and ref_eos[2]["token_ids"][-1] == eos
+    assert eng2.scheduler.block_manager.num_free_blocks == 64
+    assert all(t >= 0 for o in out_eos for t in o["token_ids"])          # no placeholder leaks out
 
 
 def test_engine_prefix_sharing_gives_same_tokens():

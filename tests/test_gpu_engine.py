@@ -126,3 +126,21 @@ def test_logits_close_on_a_mixed_step():
     err = (outs[0] - outs[1]).abs().max().item()
     scale = outs[1].abs().max().item()
     assert err <= 2e-2 * max(1.0, scale), (err, scale)
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_pipelined_decode_matches_synchronous_loop(graphs):
+    """Decode steps enqueued one ahead of the host (input tokens gathered on the device from the
+    previous step's samples) give exactly the tokens of the synchronous loop on the same kernels."""
+    cfg = ModelConfig(vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                      num_attention_heads=16, num_key_value_heads=8, head_dim=128, max_position_embeddings=4096)
+    model = build(cfg, None, True, seed=3)
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in (16, 13, 300, 255, 257, 40)]
+    params = [SamplingParams(0.0, n) for n in (40, 3, 64, 1, 33, 64)]
+    kw = dict(block_size=256, num_kvcache_blocks=24, max_num_batched_tokens=400, long_prefill_token_threshold=256,
+              device=DEV, eos=-1, use_graphs=graphs)
+    ref, _ = LLMEngine(model, cfg, **kw).generate(prompts, params)
+    out, m = LLMEngine(model, cfg, pipelined_decode=True, **kw).generate(prompts, params)
+    assert [o["token_ids"] for o in out] == [o["token_ids"] for o in ref]
+    assert m.num_generated_tokens == sum(p.max_tokens for p in params)

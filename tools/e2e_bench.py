@@ -18,7 +18,7 @@ from nanovllm_amd.model.qwen3 import ModelConfig, Qwen3ForCausalLM  # noqa: E402
 
 
 def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device="cuda:0", seed=0,
-        max_num_batched_tokens=4000, fused=True, graphs=True, fuse_gemms=True):
+        max_num_batched_tokens=4000, fused=True, graphs=True, fuse_gemms=True, pipelined=True):
     cfg = getattr(ModelConfig, model_name)()
     torch.manual_seed(seed)
     with torch.device(device):
@@ -33,7 +33,7 @@ def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device=
         model.fuse_weights()
     blocks = batch * (-(-(prompt_len + out_len) // 256)) + 8
     eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=blocks, max_num_batched_tokens=max_num_batched_tokens,
-                    device=device, eos=-1, use_graphs=graphs)
+                    device=device, eos=-1, use_graphs=graphs, pipelined_decode=pipelined)
     g = torch.Generator().manual_seed(seed)
     prompts = [torch.randint(0, cfg.vocab_size, (prompt_len,), generator=g).tolist() for _ in range(batch)]
     # warm-up (library load, hipBLASLt heuristics, decode-graph capture of the full batch) on OTHER random
@@ -45,7 +45,8 @@ def run(model_name="qwen3_0_6b", batch=256, prompt_len=512, out_len=256, device=
     outs, metrics = eng.generate(prompts, SamplingParams(0.0, out_len))
     s = metrics.summary()
     s["prefix_cache_hit_tokens"] = int(sum(o.get("cached_tokens", 0) for o in outs))
-    s.update(model=model_name, batch=batch, prompt_len=prompt_len, out_len=out_len, fused=fused, graphs=graphs, fuse_gemms=fuse_gemms)
+    s.update(model=model_name, batch=batch, prompt_len=prompt_len, out_len=out_len, fused=fused, graphs=graphs, fuse_gemms=fuse_gemms,
+             pipelined_decode=pipelined)
     return s
 
 
@@ -93,7 +94,7 @@ def run_long_context_decode(model_name="llama31_8b", batch=8, ctx=32768, out_len
     cfg, model = _build(model_name, device, seed)
     prompt_len = ctx - out_len
     eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=batch * (ctx // 256 + 1) + 8, device=device,
-                    eos=-1, use_graphs=True)
+                    eos=-1, use_graphs=True, pipelined_decode=True)
     g = torch.Generator().manual_seed(seed)
     warm = [torch.randint(0, cfg.vocab_size, (600,), generator=g).tolist() for _ in range(batch)]
     eng.generate(warm, SamplingParams(0.0, 3))
@@ -116,6 +117,7 @@ if __name__ == "__main__":
     ap.add_argument("--unfused", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fuse-gemms", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="synchronous decode loop (token values read every step)")
     ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode"])
     ap.add_argument("--ctx", type=int, default=32768)
     a = ap.parse_args()
@@ -126,4 +128,5 @@ if __name__ == "__main__":
         print(json.dumps(run_long_context_decode(a.model if a.model != "qwen3_0_6b" else "llama31_8b",
                                                  a.batch if a.batch != 256 else 8, a.ctx, a.out_len if a.out_len != 256 else 64)))
         sys.exit(0)
-    print(json.dumps(run(a.model, a.batch, a.prompt_len, a.out_len, fused=not a.unfused, graphs=not a.no_graphs, fuse_gemms=not a.no_fuse_gemms)))
+    print(json.dumps(run(a.model, a.batch, a.prompt_len, a.out_len, fused=not a.unfused, graphs=not a.no_graphs, fuse_gemms=not a.no_fuse_gemms,
+                         pipelined=not a.no_pipeline)))
