@@ -136,34 +136,50 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     // issue right after the barrier never waits on the table.
     const int tiles_per_block = p.block_size / kBN;
     auto table_entry = [&](int t) { return bt[t / tiles_per_block]; };
-    auto stage = [&](int t, int phys_entry) {
-        const int buf = t & 1;
+    // Per-lane part of a DMA source address, constant over the tiles: piece i of this wave
+    // covers cache rows (pc>>1)*8 .. +7 and four 16-byte chunks per row, picked so that the
+    // linear LDS fill produces the swizzled image.  In uint4 units relative to the tile base.
+    int dma_row[4];
+    uint32_t dma_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pc = wave * 4 + i;
+        dma_row[i] = (pc >> 1) * 8 + ((lane & 31) >> 2);
+        const int ch = (2 * (pc & 1) + (lane >> 5)) * 4 + ((lane & 3) ^ ((dma_row[i] >> 2) & 3));
+        dma_off[i] = (uint32_t)(dma_row[i] * (p.H_kv * 16) + ch);
+    }
+    // tile t -> buffer BUF (compile-time, so every LDS address below is a lane constant plus
+    // an immediate)
+    auto stage = [&](auto buf_tag, int t, int phys_entry) {
+        constexpr int BUF = decltype(buf_tag)::value;
         const int key0 = t * kBN;
         // block_size is a multiple of 64 here, so a tile sits inside one cache block
         const int off = (t % tiles_per_block) * kBN;
         int64_t phys = __builtin_amdgcn_readfirstlane(phys_entry);
         phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
         const int64_t base = ((phys * p.block_size + off) * p.H_kv + hkv) * 16;
+        const uint4* kbase = p.k_cache + base;   // wave-uniform
+        const uint4* vbase = p.v_cache + base;
         const int last = n_k - 1 - key0;  // last valid row of this tile (>= 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
-            int row = (pc >> 1) * 8 + ((lane & 31) >> 2);
-            const int ch = (2 * (pc & 1) + (lane >> 5)) * 4 + ((lane & 3) ^ ((row >> 2) & 3));
             // rows beyond the sequence re-read the last valid row: finite data, masked scores
-            row = row <= last ? row : last;
-            const int64_t vec = base + (int64_t)row * (p.H_kv * 16) + ch;
+            const uint32_t o = dma_off[i] - (uint32_t)(max(dma_row[i] - last, 0) * (p.H_kv * 16));
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(p.k_cache + vec),
-                (__attribute__((address_space(3))) void*)(lds + buf * 32768 + pc * 1024), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(kbase + o),
+                (__attribute__((address_space(3))) void*)(lds + BUF * 32768 + pc * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(p.v_cache + vec),
-                (__attribute__((address_space(3))) void*)(lds + buf * 32768 + 16384 + pc * 1024), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(vbase + o),
+                (__attribute__((address_space(3))) void*)(lds + BUF * 32768 + 16384 + pc * 1024), 16, 0, 0);
         }
     };
+    using buf0 = std::integral_constant<int, 0>;
+    using buf1 = std::integral_constant<int, 1>;
 
+    // tile t_begin + j lives in buffer j & 1
     int phys_next = 0;  // table entry of tile t+1 while tile t is computed
-    if (t_begin < nt) stage(t_begin, table_entry(t_begin));
+    if (t_begin < nt) stage(buf0{}, t_begin, table_entry(t_begin));
     if (t_begin + 1 < nt) phys_next = table_entry(t_begin + 1);
 
     const int i16 = lane & 15;
@@ -171,18 +187,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const int qpos = rw0 + r + shift;               // last visible key of this lane's query row
     const int wave_last_key = min(rw0 + 31, n_q - 1) + shift;  // last key any row of the wave sees
 
-    for (int t = t_begin; t < nt; ++t) {
+    // One tile: buffer BUF holds tile t, the other buffer receives tile t + 1.
+    auto tile_step = [&](auto buf_tag, int t) {
+        constexpr int BUF = decltype(buf_tag)::value;
         // tile t has landed for every wave, and every wave is done reading the other buffer
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int phys_use = phys_next;
         if (t + 2 < nt) phys_next = table_entry(t + 2);
-        if (t + 1 < nt) stage(t + 1, phys_use);
-        const unsigned char* ldsK = lds + (t & 1) * 32768;
+        if (t + 1 < nt) stage(std::integral_constant<int, 1 - BUF>{}, t + 1, phys_use);
+        const unsigned char* ldsK = lds + BUF * 32768;
         const unsigned char* ldsV = ldsK + 16384;
         const int kt = t * kBN;
         // wave-uniform: does this wave have any row that sees a key of this tile?
-        if (!(wave_live && kt <= wave_last_key)) continue;
+        if (!(wave_live && kt <= wave_last_key)) return;
 
         // ---------------- S^T = K . Q^T : 2 key blocks of 32 ----------------
         f32x16 sacc[2];
@@ -262,6 +280,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
                                                                   oacc[d], 0, 0, 0);
             }
         }
+    };
+
+    for (int t = t_begin; t < nt; t += 2) {
+        tile_step(buf0{}, t);
+        if (t + 1 < nt) tile_step(buf1{}, t + 1);
     }
 
     // ---- epilogue ----
