@@ -122,7 +122,7 @@ __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm,
     }
     __syncthreads();
     if (lane >= 16) return;
-    for (int g = wave; g < G; g += kDecWaves) {
+    for (int g = wave; g < p.G; g += kDecWaves) {   // p.G <= G: the template may be padded
         float mm = kNegBig;
 #pragma unroll
         for (int w = 0; w < kDecWaves; ++w) mm = fmaxf(mm, sm[(w * G + g) * kPartStride + kHeadDim]);
@@ -138,7 +138,7 @@ __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm,
             a[4] += y.x * f; a[5] += y.y * f; a[6] += y.z * f; a[7] += y.w * f;
             ls += src[kHeadDim + 1] * f;
         }
-        store_state(p, b, h * G + g, split, tq, c, mm, ls, a);
+        store_state(p, b, h * p.G + g, split, tq, c, mm, ls, a);
     }
 }
 
@@ -338,6 +338,9 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 // common tile has no cross-lane maximum at all.
 constexpr float kDecRaise = 8.0f;
 
+// G is the head count the kernel is laid out for (4 or 8); the launch may have fewer query heads per
+// kv head (p.G = 3, 5, 6, 7: e.g. 40 query / 8 kv heads): the surplus columns are zero queries whose
+// results are not stored.
 template <int G, bool ALIGNED, int kDepth, bool WGS>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     static_assert(G == 4 || G == 8, "query heads per kv head");
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < G) v = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * G + c) * 16 + 4 * s + r4];
+        if (c < p.G) v = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * p.G + c) * 16 + 4 * s + r4];
         qf[s] = __builtin_bit_cast(bf16x8, v);
     }
 
@@ -560,7 +563,8 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     }
     if (r4 != 0) return;
 #pragma unroll
-    for (int g = 0; g < G; ++g) store_state(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
+    for (int g = 0; g < G; ++g)
+        if (g < p.G) store_state(p, b, h * p.G + g, split, tq, c, m[g], l[g], acc[g]);
 }
 
 // Combine the per-chunk partial states of one (sequence, query head): 32 threads x 4 dims.
@@ -640,7 +644,8 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
 // G >= 4 runs the MFMA-score kernel (about 200 registers: one 4-wave workgroup per SIMD set and
 // CU at a time), which measured fastest with one workgroup per CU; the VALU kernel wants two.
 static bool decode_uses_mfma(int G) {
-    const char* ve = getenv("NV_DECODE_VALU");  // 1 keeps G >= 4 on the all-VALU kernel: a comparison aid
+    if (G == 3 || (G > 4 && G < 8)) return true;  // only the MFMA kernel takes a padded head count
+    const char* ve = getenv("NV_DECODE_VALU");  // 1 keeps G = 4, 8 on the all-VALU kernel: a comparison aid
     return G >= 4 && !(ve && atoi(ve) > 0);
 }
 
@@ -724,8 +729,8 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     NV_REQUIRE((int64_t)max_blocks * block_size >= max_seqlen_k, NV_ERR_INVALID_ARG,
                "nv_attn_decode_paged: block table too narrow for max_seqlen_k");
     const int G = H_q / H_kv;
-    NV_REQUIRE(G == 1 || G == 2 || G == 4 || G == 8, NV_ERR_UNSUPPORTED,
-               "nv_attn_decode_paged: H_q/H_kv = %d (supported: 1, 2, 4, 8)", G);
+    NV_REQUIRE(G >= 1 && G <= 8, NV_ERR_UNSUPPORTED,
+               "nv_attn_decode_paged: H_q/H_kv = %d (supported: 1 .. 8)", G);
 
     DecodeParams p;
     p.q = (const uint4*)q;
@@ -790,17 +795,20 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         if (aligned) NV_DEC_LAUNCH_M2(GG, true); \
         else NV_DEC_LAUNCH_M2(GG, false);        \
     } while (0)
+    // G = 3, 5, 6, 7 run the MFMA-score kernel laid out for the next of 4 / 8 heads
     switch (G) {
         case 1: NV_DEC_LAUNCH(1); break;
         case 2: NV_DEC_LAUNCH(2); break;
+        case 3: NV_DEC_LAUNCH_M(4); break;
         case 4:
             if (use_mfma) NV_DEC_LAUNCH_M(4);
             else NV_DEC_LAUNCH(4);
             break;
-        default:
+        case 8:
             if (use_mfma) NV_DEC_LAUNCH_M(8);
             else NV_DEC_LAUNCH(8);
             break;
+        default: NV_DEC_LAUNCH_M(8); break;
     }
 #undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH

@@ -53,6 +53,11 @@ class ModelConfig:
                    tie_word_embeddings=False, **kw)
 
     @classmethod
+    def qwen3_14b(cls, **kw):
+        return cls(hidden_size=5120, intermediate_size=17408, num_hidden_layers=40, num_attention_heads=40,
+                   tie_word_embeddings=False, **kw)
+
+    @classmethod
     def qwen3_32b(cls, **kw):
         return cls(hidden_size=5120, intermediate_size=25600, num_hidden_layers=64, num_attention_heads=64,
                    tie_word_embeddings=False, **kw)

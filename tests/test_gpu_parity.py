@@ -330,6 +330,24 @@ def test_decode_both_work_item_forms(hip, monkeypatch, form, H_q, H_kv, bs):
     _attn_check(_run_attention(ops, to_dev(p), "decode"), ref, f"decode-form{form}")
 
 
+@pytest.mark.parametrize("H_q,H_kv", [(12, 4), (40, 8), (24, 4), (28, 4)])
+def test_attention_odd_group_sizes(hip, H_q, H_kv):
+    """3, 5, 6 and 7 query heads per kv head (e.g. 40 / 8): decode runs the kernel laid out for the
+    next of 4 / 8 heads with zero-query surplus columns, prefill shares K/V tiles between gcd(G, 4) heads."""
+    _, ops = hip
+    n_qs, n_ks = [1, 1, 70, 1, 129], [1, 300, 70, 2049, 400]
+    p = make_paged_problem(H_q, n_qs, n_ks, H_q, H_kv, 256, 16)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    _attn_check(_run_attention(ops, pd, "mixed"), ref, "mixed")
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "prefill")
+    dec = make_paged_problem(H_q + 1, [1] * 4, [5, 64, 1000, 5000], H_q, H_kv, 256, 28)
+    ref = ref_attention.paged_attention_ref(dec["q"], dec["k_cache"], dec["v_cache"], dec["cu_q"], dec["cu_k"],
+                                            dec["block_tables"], dec["scale"])
+    _attn_check(_run_attention(ops, to_dev(dec), "decode"), ref, "decode")
+
+
 def test_decode_zero_length_sequence_gives_zeros(hip):
     _, ops = hip
     p = make_paged_problem(9, [1, 1], [0, 40], 16, 8, 256, 3)
@@ -540,7 +558,7 @@ def test_unsupported_arguments_raise(hip):
     """Shapes the kernels are not built for are refused with the library's error text, never run."""
     _, ops = hip
     from nanovllm_amd._lib import NanoVllmHipError
-    p = to_dev(make_paged_problem(1, [1, 1], [10, 20], 12, 4, 256, 3))          # 3 query heads per kv head
+    p = to_dev(make_paged_problem(1, [1, 1], [10, 20], 16, 1, 256, 3))          # 16 query heads per kv head
     with pytest.raises(NanoVllmHipError, match="H_q/H_kv"):
         _run_attention(ops, p, "decode")
     p = to_dev(make_paged_problem(1, [40], [40], 8, 4, 32, 3))                  # prefill needs block_size % 64 == 0
