@@ -1,16 +1,19 @@
 // Paged decode attention (one query token per sequence) for gfx950.
 //
-// HBM-bandwidth-bound: every K/V byte of the context is read exactly once per step, so
-// the kernel is built around keeping many 16-byte-per-lane loads in flight rather than
-// around matrix cores.
+// HBM-bandwidth-bound: every K/V byte of the context is read exactly once per step, so the
+// kernels are built around keeping many 16-byte-per-lane loads in flight.
 //
-// Work item = one WAVE = (sequence b, kv head h, key chunk s).  The wave streams its
-// chunk in tiles of 16 keys.  Lane l holds 16 bytes (8 dims) of key (l >> 4) of each
-// 4-key load: dims 8*(l & 15) .. +7, so one wave load instruction covers 4 whole
-// 256-byte K (or V) rows of the head.  Scores are v_dot2 partial sums reduced over the 16
-// lanes of a DPP row; each 16-lane row keeps its own online-softmax state (m, l, acc) for
-// the G = H_q / H_kv query heads sharing the kv head, merged once at the end of the chunk.
-// Chunks are combined by a second small kernel (or written directly when there is one).
+// Two kernels share the work decomposition and the epilogue:
+//   attn_decode_kernel       G = H_q / H_kv <= 2 (and a comparison path for 4, 8): all VALU.
+//   attn_decode_mfma_kernel  G = 3 .. 8: the scores of a 16-key tile come from four MFMAs.
+// Work item = (sequence b, kv head h, key chunk s), streamed in tiles of 16 keys.  It is one
+// WAVE (four independent items per workgroup, neighbouring kv heads of the same tokens) or,
+// for launches with few (sequence, head) pairs, one WORKGROUP whose four waves take a
+// quarter of the chunk each and merge their states in LDS.  V (and K in the VALU kernel) is
+// loaded with lane l holding 16 bytes (8 dims) of key (l >> 4) of each 4-key load, so one
+// wave load instruction covers 4 whole 256-byte rows of the head.  Every 16-lane row keeps
+// an online-softmax state (m, l, acc) for the G query heads of the kv head; rows, waves and
+// chunks are merged at the end (registers, LDS, and a second small kernel respectively).
 //
 // Semantics: flash_attn_varlen_func(..., causal=True, block_table=...) with seqlen_q == 1
 // as called at nanovllm/layers/attention.py:241-252 (the query sees every cached key,
