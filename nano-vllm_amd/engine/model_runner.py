@@ -221,7 +221,9 @@ class ModelRunner:
         return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
 
     def _graph_for(self, n_seqs: int, table_width: int) -> _DecodeGraph:
-        batch = -(-n_seqs // 16) * 16
+        # batch buckets: 1, 2, 4, 8, then multiples of 16 (the kernels plan their launch from the padded
+        # batch, so padding a small batch to 16 would halve its useful waves)
+        batch = 1 << max(0, int(n_seqs - 1).bit_length()) if n_seqs <= 8 else -(-n_seqs // 16) * 16
         width = 1 << max(0, int(table_width - 1).bit_length())     # next power of two
         g = self._graphs.get((batch, width))
         if g is None:
