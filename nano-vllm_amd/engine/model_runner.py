@@ -224,7 +224,11 @@ class ModelRunner:
         # batch buckets: 1, 2, 4, 8, then multiples of 16 (the kernels plan their launch from the padded
         # batch, so padding a small batch to 16 would halve its useful waves)
         batch = 1 << max(0, int(n_seqs - 1).bit_length()) if n_seqs <= 8 else -(-n_seqs // 16) * 16
-        width = 1 << max(0, int(table_width - 1).bit_length())     # next power of two
+        # table width buckets: powers of two up to 8 blocks, then four per octave (the captured launch
+        # plans for width * block_size keys, so a coarse bucket would leave half of its key chunks empty)
+        p2 = 1 << max(0, int(table_width - 1).bit_length())
+        step = max(1, p2 // 8)
+        width = p2 if p2 <= 8 else -(-table_width // step) * step
         g = self._graphs.get((batch, width))
         if g is None:
             # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
