@@ -47,6 +47,16 @@ def test_argument_errors_are_reported_without_a_gpu():
         _lib.check(-1, "x")
 
 
+def test_header_and_library_from_plain_c(tmp_path):
+    """The header is C (not only C++) and the library binds from a plain C program via dlopen."""
+    import subprocess
+    exe = str(tmp_path / "cabi_from_c")
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi_from_c.c"), "-o", exe, "-ldl"], check=True)
+    out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _lib.load(str(tmp_path / "nope.so"))
