@@ -272,3 +272,35 @@ def test_llama3_rope_scaling_matches_transformers():
     base = 1.0 / (5e5 ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128))
     got = llama3_scale_inv_freq(base, 8.0, 1.0, 4.0, 8192)
     assert torch.allclose(got, want, rtol=1e-6, atol=0)
+
+
+def test_safetensors_loader_round_trip(tmp_path):
+    """Weights written as HF-style safetensors shards load back by parameter name, unknown tensors are
+    reported, a missing parameter is an error, and a head-sharded model takes only its rows."""
+    from safetensors.torch import save_file
+    from nanovllm_amd.parallel import HeadShard
+    from nanovllm_amd.utils.loader import load_model
+    cfg = ModelConfig(vocab_size=128, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                      num_attention_heads=4, num_key_value_heads=2, head_dim=128, max_position_embeddings=256,
+                      tie_word_embeddings=False)
+    torch.manual_seed(0)
+    src = Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False)
+    for p in src.parameters():
+        torch.nn.init.normal_(p, 0.0, 0.1)
+    sd = {k: v.contiguous() for k, v in src.state_dict().items()}
+    names = sorted(sd)
+    save_file({k: sd[k] for k in names[::2]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({**{k: sd[k] for k in names[1::2]}, "rotary.inv_freq": torch.zeros(4)},
+              str(tmp_path / "model-00002-of-00002.safetensors"))
+    dst = Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False)
+    assert load_model(dst, str(tmp_path)) == ["rotary.inv_freq"]
+    assert all(torch.equal(a, b) for a, b in zip(src.state_dict().values(), dst.state_dict().values()))
+    part = Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False, shard=HeadShard(1, 2, 4, 2))
+    load_model(part, str(tmp_path))
+    q = src.state_dict()["model.layers.1.self_attn.q_proj.weight"]
+    assert torch.equal(part.state_dict()["model.layers.1.self_attn.q_proj.weight"], q[256:512])
+    os.remove(tmp_path / "model-00001-of-00002.safetensors")
+    with pytest.raises(KeyError):
+        load_model(Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False), str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        load_model(dst, str(tmp_path / "nowhere"))
