@@ -144,3 +144,25 @@ def test_pipelined_decode_matches_synchronous_loop(graphs):
     out, m = LLMEngine(model, cfg, pipelined_decode=True, **kw).generate(prompts, params)
     assert [o["token_ids"] for o in out] == [o["token_ids"] for o in ref]
     assert m.num_generated_tokens == sum(p.max_tokens for p in params)
+
+
+def test_prefix_cache_hit_gives_the_same_tokens_on_the_hip_path():
+    """A second request sharing two full cache blocks with an earlier one skips them (chunked prefill
+    with keys already cached: the bottom-right mask of the prefill kernel) and must produce the tokens
+    of an engine that computes the whole prompt."""
+    cfg = ModelConfig(vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                      num_attention_heads=16, num_key_value_heads=8, head_dim=128, max_position_embeddings=4096)
+    model = build(cfg, None, True, seed=5)
+    g = torch.Generator().manual_seed(12)
+    shared = torch.randint(0, cfg.vocab_size, (512,), generator=g).tolist()
+    p1 = shared + torch.randint(0, cfg.vocab_size, (40,), generator=g).tolist()
+    p2 = shared + torch.randint(0, cfg.vocab_size, (75,), generator=g).tolist()
+    kw = dict(block_size=256, num_kvcache_blocks=16, max_num_batched_tokens=400, long_prefill_token_threshold=256,
+              device=DEV, eos=-1, use_graphs=True, pipelined_decode=True)
+    eng = LLMEngine(model, cfg, **kw)
+    eng.generate([p1], SamplingParams(0.0, 8))
+    out, _ = eng.generate([p2], SamplingParams(0.0, 24))
+    assert out[0]["cached_tokens"] == 512
+    fresh, _ = LLMEngine(model, cfg, **kw).generate([p2], SamplingParams(0.0, 24))
+    assert fresh[0]["cached_tokens"] == 0
+    assert out[0]["token_ids"] == fresh[0]["token_ids"]
