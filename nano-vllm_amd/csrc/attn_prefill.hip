@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     // load: the compiler will not use a scalar load next to LDS-DMA writes), so the DMA
     // issue right after the barrier never waits on the table.
     const int tiles_per_block = p.block_size / kBN;
-    auto table_entry = [&](int t) { return bt[t / tiles_per_block]; };
+    const int row_vec = p.H_kv * 16;                                   // uint4 per cache token row
+    const int64_t block_vec = (int64_t)p.block_size * row_vec;         // uint4 per cache block
     // Per-lane part of a DMA source address, constant over the tiles: piece i of this wave
     // covers cache rows (pc>>1)*8 .. +7 and four 16-byte chunks per row, picked so that the
     // linear LDS fill produces the swizzled image.  In uint4 units relative to the tile base.
@@ -146,26 +147,24 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         const int pc = wave * 4 + i;
         dma_row[i] = (pc >> 1) * 8 + ((lane & 31) >> 2);
         const int ch = (2 * (pc & 1) + (lane >> 5)) * 4 + ((lane & 3) ^ ((dma_row[i] >> 2) & 3));
-        dma_off[i] = (uint32_t)(dma_row[i] * (p.H_kv * 16) + ch);
+        dma_off[i] = (uint32_t)(dma_row[i] * row_vec + ch);
     }
     // tile t -> buffer BUF (compile-time, so every LDS address below is a lane constant plus
     // an immediate)
-    auto stage = [&](auto buf_tag, int t, int phys_entry) {
+    // block_size is a multiple of 64 here, so a tile sits inside one cache block: it is named by
+    // its table entry and its key offset `off` inside the block; `last` = last valid row of the tile.
+    auto stage = [&](auto buf_tag, int phys_entry, int off, int last) {
         constexpr int BUF = decltype(buf_tag)::value;
-        const int key0 = t * kBN;
-        // block_size is a multiple of 64 here, so a tile sits inside one cache block
-        const int off = (t % tiles_per_block) * kBN;
         int64_t phys = __builtin_amdgcn_readfirstlane(phys_entry);
         phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
-        const int64_t base = ((phys * p.block_size + off) * p.H_kv + hkv) * 16;
+        const int64_t base = phys * block_vec + off * row_vec + hkv * 16;
         const uint4* kbase = p.k_cache + base;   // wave-uniform
         const uint4* vbase = p.v_cache + base;
-        const int last = n_k - 1 - key0;  // last valid row of this tile (>= 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
             // rows beyond the sequence re-read the last valid row: finite data, masked scores
-            const uint32_t o = dma_off[i] - (uint32_t)(max(dma_row[i] - last, 0) * (p.H_kv * 16));
+            const uint32_t o = dma_off[i] - (uint32_t)(max(dma_row[i] - last, 0) * row_vec);
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(kbase + o),
                 (__attribute__((address_space(3))) void*)(lds + BUF * 32768 + pc * 1024), 16, 0, 0);
@@ -178,9 +177,16 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     using buf1 = std::integral_constant<int, 1>;
 
     // tile t_begin + j lives in buffer j & 1
+    // Tile bookkeeping is incremental (no divisions in the loop): st_* names the tile staged next
+    // (t + 1), pf_* the tile whose table entry is fetched next (t + 2).
     int phys_next = 0;  // table entry of tile t+1 while tile t is computed
-    if (t_begin < nt) stage(buf0{}, t_begin, table_entry(t_begin));
-    if (t_begin + 1 < nt) phys_next = table_entry(t_begin + 1);
+    if (t_begin < nt)
+        stage(buf0{}, bt[t_begin / tiles_per_block], (t_begin % tiles_per_block) * kBN, n_k - 1 - t_begin * kBN);
+    if (t_begin + 1 < nt) phys_next = bt[(t_begin + 1) / tiles_per_block];
+    int st_off = ((t_begin + 1) % tiles_per_block) * kBN;
+    int st_last = n_k - 1 - (t_begin + 1) * kBN;
+    int pf_blk = (t_begin + 2) / tiles_per_block;
+    int pf_off = ((t_begin + 2) % tiles_per_block) * kBN;
 
     const int i16 = lane & 15;
     const int g16 = (lane >> 4) & 1;
@@ -194,8 +200,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int phys_use = phys_next;
-        if (t + 2 < nt) phys_next = table_entry(t + 2);
-        if (t + 1 < nt) stage(std::integral_constant<int, 1 - BUF>{}, t + 1, phys_use);
+        if (t + 2 < nt) phys_next = bt[pf_blk];
+        if (t + 1 < nt) stage(std::integral_constant<int, 1 - BUF>{}, phys_use, st_off, st_last);
+        st_off = st_off + kBN == p.block_size ? 0 : st_off + kBN;
+        st_last -= kBN;
+        pf_off += kBN;
+        if (pf_off == p.block_size) {
+            pf_off = 0;
+            ++pf_blk;
+        }
         const unsigned char* ldsK = lds + BUF * 32768;
         const unsigned char* ldsV = ldsK + 16384;
         const int kt = t * kBN;
