@@ -137,9 +137,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const int tiles_per_block = p.block_size / kBN;
     const int row_vec = p.H_kv * 16;                                   // uint4 per cache token row
     const int64_t block_vec = (int64_t)p.block_size * row_vec;         // uint4 per cache block
+    const int max_block = (int)(p.num_blocks - 1 < 0x7fffffff ? p.num_blocks - 1 : 0x7fffffff);
     // Per-lane part of a DMA source address, constant over the tiles: piece i of this wave
     // covers cache rows (pc>>1)*8 .. +7 and four 16-byte chunks per row, picked so that the
-    // linear LDS fill produces the swizzled image.  In uint4 units relative to the tile base.
+    // linear LDS fill produces the swizzled image.  In bytes relative to the tile base (a tile
+    // spans 64 cache rows, far below 4 GiB).
     int dma_row[4];
     uint32_t dma_off[4];
 #pragma unroll
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         const int pc = wave * 4 + i;
         dma_row[i] = (pc >> 1) * 8 + ((lane & 31) >> 2);
         const int ch = (2 * (pc & 1) + (lane >> 5)) * 4 + ((lane & 3) ^ ((dma_row[i] >> 2) & 3));
-        dma_off[i] = (uint32_t)(dma_row[i] * row_vec + ch);
+        dma_off[i] = (uint32_t)(dma_row[i] * row_vec + ch) * 16u;   // bytes
     }
     // tile t -> buffer BUF (compile-time, so every LDS address below is a lane constant plus
     // an immediate)
@@ -155,21 +157,28 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     // its table entry and its key offset `off` inside the block; `last` = last valid row of the tile.
     auto stage = [&](auto buf_tag, int phys_entry, int off, int last) {
         constexpr int BUF = decltype(buf_tag)::value;
-        int64_t phys = __builtin_amdgcn_readfirstlane(phys_entry);
-        phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
-        const int64_t base = phys * block_vec + off * row_vec + hkv * 16;
-        const uint4* kbase = p.k_cache + base;   // wave-uniform
-        const uint4* vbase = p.v_cache + base;
+        int phys = __builtin_amdgcn_readfirstlane(phys_entry);
+        phys = phys < 0 ? 0 : (phys > max_block ? max_block : phys);
+        const int64_t base = (int64_t)phys * block_vec + off * row_vec + hkv * 16;
+        const char* kbase = reinterpret_cast<const char*>(p.k_cache + base);   // wave-uniform
+        const char* vbase = reinterpret_cast<const char*>(p.v_cache + base);
+        uint32_t o[4];
+        if (last >= kBN - 1) {  // wave-uniform: every row of the tile exists
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = dma_off[i];
+        } else {
+            // rows beyond the sequence re-read the last valid row: finite data, masked scores
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = dma_off[i] - (uint32_t)(max(dma_row[i] - last, 0) * row_vec) * 16u;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pc = wave * 4 + i;
-            // rows beyond the sequence re-read the last valid row: finite data, masked scores
-            const uint32_t o = dma_off[i] - (uint32_t)(max(dma_row[i] - last, 0) * row_vec);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(kbase + o),
+                (const __attribute__((address_space(1))) void*)(kbase + o[i]),
                 (__attribute__((address_space(3))) void*)(lds + BUF * 32768 + pc * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(vbase + o),
+                (const __attribute__((address_space(1))) void*)(vbase + o[i]),
                 (__attribute__((address_space(3))) void*)(lds + BUF * 32768 + 16384 + pc * 1024), 16, 0, 0);
         }
     };
