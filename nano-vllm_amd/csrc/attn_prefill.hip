@@ -44,7 +44,7 @@ struct PrefillParams {
     const int32_t* block_tables;
     int B, max_blocks, H_q, H_kv, block_size;
     int hpw;          // query heads per workgroup (divides G and 4)
-    int rows_per_wg;  // 32 * QB * (4 / hpw)
+    int rows_per_wg;  // 32 * (4 / hpw)
     int n_qtiles;     // ceil(max_seqlen_q / rows_per_wg)
     int wg_per_pair;  // n_qtiles * (G / hpw): workgroups of one (sequence, kv head)
     int n_pairs;      // B * H_kv
@@ -68,10 +68,7 @@ __device__ __forceinline__ int tile_off(int row, int ch) {
     return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
 
-// QB = 32-row query blocks per wave: 1 (two workgroups per CU) or 2 (one workgroup per CU, the
-// whole register file per wave; every K and V^T fragment read from LDS feeds two MFMAs).
-template <int QB>
-__global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(const PrefillParams p) {
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParams p) {
     // [2 buffers][K tile 16 KiB | V tile 16 KiB]; the only LDS object of the kernel
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 32768];
 
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
     if (n_q <= 0 || q0 >= n_q) return;
     if (p.skip_single && n_q == 1) return;
     const int shift = n_k - n_q;                        // query i sees keys <= i + shift
-    const int rw0 = q0 + (wave / p.hpw) * (32 * QB);    // first query row of the wave
+    const int rw0 = q0 + (wave / p.hpw) * 32;           // first query row of the wave
     const bool wave_live = rw0 < n_q;
     const int last_row = min(q0 + p.rows_per_wg, n_q) - 1;
     const int max_key = min(last_row + shift, n_k - 1);  // last key any row here can see
@@ -113,23 +110,21 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
     const int nt = min(nt_all, t_begin + p.tiles_per_split);  // this split covers tiles t_begin .. nt-1
 
     // ---- Q fragments: B operand of S^T, lane (r, h) holds Q[row r][16s + 8h .. +7] ----
-    bf16x8 qf[QB][8];
-    f32x16 oacc[QB][4];
-    float m_run[QB];  // reference max of the exponentials (log2 domain), lanes l and l^32 agree
-    float l_run[QB];  // this lane's share of the running denominator
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int row = min(rw0 + 32 * qb + r, n_q - 1);
+    bf16x8 qf[8];
+    {
+        const int row = min(rw0 + r, n_q - 1);
         const uint4* qp = p.q + (int64_t)(q_begin + row) * p.q_stride_vec + (int64_t)hq * 16;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) qf[qb][s] = __builtin_bit_cast(bf16x8, qp[2 * s + h]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[qb][d][i] = 0.f;
-        m_run[qb] = kRunInit;
-        l_run[qb] = 0.f;
+        for (int s = 0; s < 8; ++s) qf[s] = __builtin_bit_cast(bf16x8, qp[2 * s + h]);
     }
+
+    f32x16 oacc[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+    float m_run = kRunInit;  // reference max of the exponentials (log2 domain), lanes l and l^32 agree
+    float l_run = 0.f;       // this lane's share of the running denominator
 
     // ---- staging: K/V tiles go global -> LDS by LDS-DMA (no registers), double-buffered.
     // One DMA wave-instruction fills 1 KiB of LDS linearly (lane l -> byte 16 l), i.e. two
@@ -204,8 +199,8 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
 
     const int i16 = lane & 15;
     const int g16 = (lane >> 4) & 1;
-    const int qpos0 = rw0 + r + shift;              // last visible key of this lane's row of block 0
-    const int wave_last_key = min(rw0 + 32 * QB - 1, n_q - 1) + shift;  // last key any row of the wave sees
+    const int qpos = rw0 + r + shift;               // last visible key of this lane's query row
+    const int wave_last_key = min(rw0 + 31, n_q - 1) + shift;  // last key any row of the wave sees
 
     // One tile: buffer BUF holds tile t, the other buffer receives tile t + 1.
     auto tile_step = [&](auto buf_tag, int t) {
@@ -230,76 +225,65 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
         if (!(wave_live && kt <= wave_last_key)) return;
 
         // ---------------- S^T = K . Q^T : 2 key blocks of 32 ----------------
-        f32x16 sacc[QB][2];
+        f32x16 sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) sacc[qb][kb][i] = 0.f;
+            for (int i = 0; i < 16; ++i) sacc[kb][i] = 0.f;
             const int row = kb * 32 + r;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const bf16x8 a = __builtin_bit_cast(
                     bf16x8, *reinterpret_cast<const uint4*>(ldsK + tile_off(row, 2 * s + h)));
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    sacc[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][s], sacc[qb][kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
             }
         }
         // ---------------- online softmax over the 64 keys (raw scores, scale folded in) ----
-        // register i of block kb is key kt + kb*32 + (i&3) + 8*(i>>2) + 4h; query row rw0 + 32 qb + r
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) {
-            if (kt + kBN - 1 > rw0 + 32 * qb + shift) {  // wave-uniform: the tile touches this block's diagonal
-                const int qpos = qpos0 + 32 * qb;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = kt + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        sacc[qb][kb][i] = key <= qpos ? sacc[qb][kb][i] : -INFINITY;
-                    }
-            }
-            float tmax = sacc[qb][0][0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[qb][0][i]);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[qb][1][i]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale_log2;
-            if (!__all(tmax <= m_run[qb] + kRescaleThreshold)) {  // rare after the first tiles
-                const float m_new = fmaxf(m_run[qb], tmax);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-                m_run[qb] = m_new;
-                l_run[qb] *= alpha;
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) oacc[qb][d][i] *= alpha;
-            }
-            float psum = 0.f;
+        // register i of block kb is key kt + kb*32 + (i&3) + 8*(i>>2) + 4h; query row rw0 + r
+        if (kt + kBN - 1 > rw0 + shift) {  // wave-uniform: the tile touches the diagonal
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const float e =
-                        __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[qb][kb][i], p.scale_log2, -m_run[qb]));
-                    sacc[qb][kb][i] = e;
-                    psum += e;
+                    const int key = kt + kb * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    sacc[kb][i] = key <= qpos ? sacc[kb][i] : -INFINITY;
                 }
-            l_run[qb] += psum;
         }
+        float tmax = sacc[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[1][i]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale_log2;
+        if (!__all(tmax <= m_run + kRescaleThreshold)) {  // rare after the first tiles
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], p.scale_log2, -m_run));
+                sacc[kb][i] = e;
+                psum += e;
+            }
+        l_run += psum;
 
         // ---------------- O^T += V^T . P^T : 4 k-steps of 16 keys ----------------
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int kb = s >> 1;
             const int s2 = s & 1;
-            bf16x8 pb[QB];
+            bf16x8 pb;
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[qb][j] = (__bf16)sacc[qb][kb][8 * s2 + j];
+            for (int j = 0; j < 8; ++j) pb[j] = (__bf16)sacc[kb][8 * s2 + j];
             // keys of element j: kb*32 + 16*s2 + 8*(j>>2) + 4h + (j&3)
             const int row1 = kb * 32 + 16 * s2 + 4 * h + (i16 >> 2);
             const int row2 = row1 + 8;
@@ -314,10 +298,8 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
                 s16x8 va;
                 va[0] = v1[0]; va[1] = v1[1]; va[2] = v1[2]; va[3] = v1[3];
                 va[4] = v2[0]; va[5] = v2[1]; va[6] = v2[2]; va[7] = v2[3];
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb)
-                    oacc[qb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), pb[qb],
-                                                                          oacc[qb][d], 0, 0, 0);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, va), pb,
+                                                                  oacc[d], 0, 0, 0);
             }
         }
     };
@@ -332,62 +314,56 @@ __global__ __launch_bounds__(256, QB == 1 ? 2 : 1) void attn_prefill_kernel(cons
     // stands every store instruction would touch 32 rows.  The tile buffers are free now,
     // so each wave transposes through its own LDS area (32 rows x 256 B, row stride 272 B:
     // conflict-free both ways) and writes whole 256-byte row segments, 4 rows per instruction.
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
     __syncthreads();  // every wave is done reading K/V tiles
     if (!wave_live) return;
     unsigned char* stg = lds + wave * (32 * 272);
+    const int rows_here = n_q - rw0;  // rows of this wave that exist (>= 1)
+    auto flush = [&](unsigned char* gbase, int64_t row_bytes) {
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-        const int rq0 = rw0 + 32 * qb;       // first row of this block
-        const int rows_here = n_q - rq0;     // rows of the block that exist
-        if (rows_here <= 0) break;           // wave-uniform
-        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
-        auto flush = [&](unsigned char* gbase, int64_t row_bytes) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int rr = 4 * it + (lane >> 4);
-                const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * 272 + (lane & 15) * 16);
-                if (rr < rows_here) *reinterpret_cast<uint4*>(gbase + rr * row_bytes + (lane & 15) * 16) = v;
-            }
-        };
-        if (p.nsplit > 1) {
-            // unnormalised state of this key range; an empty range leaves l = 0 and is skipped
-            // by the merge, so its accumulators need not be written
-            float* dst0 = p.part + (((int64_t)(q_begin + rq0) * p.H_q + hq) * p.nsplit + split) * kPartStride;
-            const int64_t row_bytes = (int64_t)p.H_q * p.nsplit * kPartStride * 4;
-            if (h == 0 && r < rows_here) {
-                float* dst = dst0 + (int64_t)r * (row_bytes / 4);
-                dst[kHeadDim] = m_run[qb];
-                dst[kHeadDim + 1] = l_tot;
-            }
-            if (t_begin >= nt) continue;
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {  // 64 fp32 dims = 256 B per pass
-#pragma unroll
-                for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int d = 2 * half + dd;
-                        *reinterpret_cast<float4*>(stg + r * 272 + (dd * 32 + 8 * g + 4 * h) * 4) =
-                            make_float4(oacc[qb][d][4 * g], oacc[qb][d][4 * g + 1], oacc[qb][d][4 * g + 2],
-                                        oacc[qb][d][4 * g + 3]);
-                    }
-                flush(reinterpret_cast<unsigned char*>(dst0) + half * 256, row_bytes);
-            }
-            continue;
+        for (int it = 0; it < 8; ++it) {
+            const int rr = 4 * it + (lane >> 4);
+            const uint4 v = *reinterpret_cast<const uint4*>(stg + rr * 272 + (lane & 15) * 16);
+            if (rr < rows_here) *reinterpret_cast<uint4*>(gbase + rr * row_bytes + (lane & 15) * 16) = v;
         }
-        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    };
+    if (p.nsplit > 1) {
+        // unnormalised state of this key range; an empty range leaves l = 0 and is skipped
+        // by the merge, so its accumulators need not be written
+        float* dst0 = p.part + (((int64_t)(q_begin + rw0) * p.H_q + hq) * p.nsplit + split) * kPartStride;
+        const int64_t row_bytes = (int64_t)p.H_q * p.nsplit * kPartStride * 4;
+        if (h == 0 && r < rows_here) {
+            float* dst = dst0 + (int64_t)r * (row_bytes / 4);
+            dst[kHeadDim] = m_run;
+            dst[kHeadDim + 1] = l_tot;
+        }
+        if (t_begin >= nt) return;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int half = 0; half < 2; ++half) {  // 64 fp32 dims = 256 B per pass
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16(oacc[qb][d][4 * g] * inv, oacc[qb][d][4 * g + 1] * inv);
-                w.y = pack_bf16(oacc[qb][d][4 * g + 2] * inv, oacc[qb][d][4 * g + 3] * inv);
-                *reinterpret_cast<uint2*>(stg + r * 272 + (d * 32 + 8 * g + 4 * h) * 2) = w;
-            }
-        flush(reinterpret_cast<unsigned char*>(p.o + (int64_t)(q_begin + rq0) * p.o_stride + (int64_t)hq * kHeadDim),
-              p.o_stride * 2);
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 2 * half + dd;
+                    *reinterpret_cast<float4*>(stg + r * 272 + (dd * 32 + 8 * g + 4 * h) * 4) =
+                        make_float4(oacc[d][4 * g], oacc[d][4 * g + 1], oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+                }
+            flush(reinterpret_cast<unsigned char*>(dst0) + half * 256, row_bytes);
+        }
+        return;
     }
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_bf16(oacc[d][4 * g] * inv, oacc[d][4 * g + 1] * inv);
+            w.y = pack_bf16(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(stg + r * 272 + (d * 32 + 8 * g + 4 * h) * 2) = w;
+        }
+    flush(reinterpret_cast<unsigned char*>(p.o + (int64_t)(q_begin + rw0) * p.o_stride + (int64_t)hq * kHeadDim),
+          p.o_stride * 2);
 }
 
 // Combine the key-range states of one query row: block = 8 (row, head) pairs x 32 threads
@@ -433,7 +409,7 @@ __global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const PrefillPa
 static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 
 struct PrefillShape {
-    int nw, qb, hpw, rows_per_wg, n_qtiles, wg_per_pair, n_pairs;
+    int nw, hpw, rows_per_wg, n_qtiles, wg_per_pair, n_pairs;
     int64_t grid_base;
     int nsplit, tiles_per_split;
 };
@@ -445,10 +421,8 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     PrefillShape sh;
     const int G = H_q / H_kv;
     sh.nw = 4;
-    const char* qe = getenv("NV_PREFILL_QB");  // 1 or 2 query blocks per wave: a tuning aid
-    sh.qb = qe && atoi(qe) == 2 ? 2 : 1;
     sh.hpw = gcd_int(G, sh.nw);
-    sh.rows_per_wg = 32 * sh.qb * (sh.nw / sh.hpw);
+    sh.rows_per_wg = 32 * (sh.nw / sh.hpw);
     sh.n_qtiles = (max_seqlen_q + sh.rows_per_wg - 1) / sh.rows_per_wg;
     sh.wg_per_pair = sh.n_qtiles * (G / sh.hpw);
     sh.n_pairs = B * H_kv;
@@ -552,10 +526,7 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     const int64_t grid = sh.grid_base * sh.nsplit;
     NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
     hipStream_t st = (hipStream_t)stream;
-    if (sh.qb == 2)
-        hipLaunchKernelGGL(attn_prefill_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL(attn_prefill_kernel<1>, dim3((unsigned)grid), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     int rc = check_launch("nv_attn_prefill_varlen");
     if (rc != NV_OK || sh.nsplit == 1) return rc;
     hipLaunchKernelGGL(attn_prefill_merge_kernel,
