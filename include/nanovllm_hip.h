@@ -69,6 +69,9 @@ NV_API int nv_store_kvcache(const void* k, const void* v, void* k_cache, void* v
  *   workspace: device scratch of at least nv_attn_decode_workspace_bytes(...) bytes,
  *   16-byte aligned; contents need no initialisation.
  * Sequences with zero keys produce zeros.
+ * Shapes: H_q a multiple of H_kv with 1 <= H_q / H_kv <= 8 (NV_ERR_UNSUPPORTED beyond);
+ * any block_size >= 1 (multiples of 16 resolve the block once per 16 keys);
+ * max_blocks * block_size >= max_seqlen_k.
  */
 NV_API int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k);
 NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* v_cache, void* o,
@@ -94,6 +97,8 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  *   would have too few workgroups for the chip (few long sequences): the key range is then
  *   split over several workgroups and a second launch combines their states.
  * Rows with no visible key produce zeros.
+ * Shapes: H_q a multiple of H_kv (any ratio); block_size a multiple of 64
+ * (NV_ERR_UNSUPPORTED otherwise); max_blocks * block_size >= max_seqlen_k.
  */
 NV_API int64_t nv_attn_prefill_workspace_bytes(int B, int total_q, int max_seqlen_q, int max_seqlen_k,
                                         int H_q, int H_kv, int D);
