@@ -1,6 +1,7 @@
 // Does a v_mfma_f32_32x32x16_bf16 whose accumulator sits in ordinary registers ("v") keep the VALU
 // of its SIMD from issuing, compared with an accumulator in accumulation registers ("a")?
-// Each wave runs ITER x { 1 MFMA + F independent v_fma_f32 } and reports cycles per MFMA.
+// Each wave runs ITER x { 1 MFMA + F independent v_fma_f32 } ("2acc": two independent accumulation
+// chains alternate) and reports cycles per MFMA.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_valu_overlap mfma_valu_overlap.hip && ./mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -9,17 +10,19 @@
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-template <bool ACC_A, int F>
+template <bool ACC_A, int F, int NACC>
 __global__ void k(float* out, long long* cycles, int iters) {
-    f32x16 acc;
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    f32x16 acc, acc2;
+    for (int i = 0; i < 16; ++i) acc[i] = acc2[i] = 0.f;
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * threadIdx.x); b[i] = (__bf16)1.0f; }
     float f[8];
     for (int i = 0; i < 8; ++i) f[i] = threadIdx.x * 0.5f + i;
     const float c1 = 1.0001f, c2 = 0.5f;
-    if constexpr (ACC_A) asm volatile("" : "+a"(acc)); else asm volatile("" : "+v"(acc));
+    if constexpr (ACC_A) asm volatile("" : "+a"(acc), "+a"(acc2)); else asm volatile("" : "+v"(acc), "+v"(acc2));
+    asm volatile("" : "+v"(a), "+v"(b));  // loop-invariant operands stay in their registers
     long long t0 = __builtin_readcyclecounter();
+#pragma unroll 4
     for (int it = 0; it < iters; ++it) {
         if constexpr (ACC_A)
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
@@ -28,27 +31,36 @@ __global__ void k(float* out, long long* cycles, int iters) {
 #pragma unroll
         for (int j = 0; j < F; ++j)
             asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j % 8]) : "v"(c1), "v"(c2));
+        if constexpr (NACC == 2) {  // a second, independent accumulation chain
+            if constexpr (ACC_A)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2) : "v"(a), "v"(b));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+#pragma unroll
+            for (int j = 0; j < F; ++j)
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j % 8]) : "v"(c1), "v"(c2));
+        }
     }
     long long t1 = __builtin_readcyclecounter();
     asm volatile("s_nop 15\n\ts_nop 15");
     float s = 0.f;
-    if constexpr (ACC_A) asm volatile("" : "+a"(acc)); else asm volatile("" : "+v"(acc));
-    for (int i = 0; i < 16; ++i) s += acc[i];
+    if constexpr (ACC_A) asm volatile("" : "+a"(acc), "+a"(acc2)); else asm volatile("" : "+v"(acc), "+v"(acc2));
+    for (int i = 0; i < 16; ++i) s += acc[i] + acc2[i];
     for (int i = 0; i < 8; ++i) s += f[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
 }
 
-template <bool ACC_A, int F>
+template <bool ACC_A, int F, int NACC = 1>
 void run(int threads, const char* name) {
     const int blocks = 256, iters = 4000;
     float* out; long long* cyc;
     hipMalloc(&out, sizeof(float) * blocks * threads);
     hipMalloc(&cyc, sizeof(long long) * blocks * (threads / 64));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<ACC_A, F><<<blocks, threads>>>(out, cyc, iters);
+    k<ACC_A, F, NACC><<<blocks, threads>>>(out, cyc, iters);
     hipEventRecord(e0);
-    k<ACC_A, F><<<blocks, threads>>>(out, cyc, iters);
+    k<ACC_A, F, NACC><<<blocks, threads>>>(out, cyc, iters);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -57,7 +69,7 @@ void run(int threads, const char* name) {
     double avg = 0; for (auto v : h) avg += v; avg /= h.size();
     // s_memtime-style counter runs at 100 MHz on this chip; report wall ns per MFMA per wave as well
     printf("%-8s acc=%s F=%d waves/SIMD=%d: %.1f ns per MFMA per wave (kernel %.3f ms), counter ticks/MFMA %.2f\n", name,
-           ACC_A ? "a" : "v", F, threads / 256, ms * 1e6 / iters, ms, avg / iters);
+           ACC_A ? "a" : "v", F, threads / 256, ms * 1e6 / (iters * NACC), ms, avg / (iters * NACC));
     hipFree(out); hipFree(cyc);
 }
 
@@ -71,6 +83,11 @@ int main() {
         run<true, 6>(threads, "mfma+6");
         run<false, 12>(threads, "mfma+12");
         run<true, 12>(threads, "mfma+12");
+        run<false, 0, 2>(threads, "2acc");
+        run<false, 4, 2>(threads, "2acc+4");
+        run<false, 6, 2>(threads, "2acc+6");
+        run<true, 6, 2>(threads, "2acc+6");
+        run<false, 12, 2>(threads, "2acc+12");
     }
     return 0;
 }
