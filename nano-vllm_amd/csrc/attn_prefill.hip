@@ -64,6 +64,18 @@ struct PrefillParams {
 // of 16-byte chunk `ch` (0..15) of row `row`.  Conflict-free for the ds_read_b128 row
 // reads of the K tile and the transposed reads of the V tile, and every read address of
 // a lane is one of two lane constants plus a compile-time immediate.
+// Lanes l and l ^ 32 exchange a value with one VALU instruction (v_permlane32_swap) instead of
+// a round trip through the LDS crossbar (ds_bpermute), which sits on the critical path of
+// every tile's softmax.
+__device__ __forceinline__ float max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ int tile_off(int row, int ch) {
     return 2048 * (row >> 3) + 512 * (ch >> 2) + 64 * (row & 7) + 16 * ((ch & 3) ^ ((row >> 2) & 3));
 }
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[0][i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[1][i]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * p.scale_log2;
+        tmax = max_xor32(tmax) * p.scale_log2;
         if (!__all(tmax <= m_run + kRescaleThreshold)) {  // rare after the first tiles
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -314,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     // stands every store instruction would touch 32 rows.  The tile buffers are free now,
     // so each wave transposes through its own LDS area (32 rows x 256 B, row stride 272 B:
     // conflict-free both ways) and writes whole 256-byte row segments, 4 rows per instruction.
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = sum_xor32(l_run);
     __syncthreads();  // every wave is done reading K/V tiles
     if (!wave_live) return;
     unsigned char* stg = lds + wave * (32 * 272);
