@@ -41,6 +41,27 @@ NV_API const char* nv_last_error(void);
 NV_API int nv_abi_version(void);
 
 /*
+ * Launch-plan overrides (measurement and test aid; no counterpart in the reference, whose
+ * flash-attn dependency picks its own splits).  The library reads NO environment variables: the
+ * only way to steer kernel selection is this process-wide setting.  Every field's "heuristic"
+ * value (the value after nv_set_tuning(NULL)) lets the library choose.  nv_attn_*_workspace_bytes
+ * and the matching launch compute their plan from the same setting, so it must not change between
+ * the two calls (a launch whose plan outgrew the workspace answers NV_ERR_WORKSPACE, never
+ * overruns it).  Not meant to be changed while launches are being issued from other threads.
+ */
+typedef struct nv_tuning {
+    int decode_target_waves;  /* 0 = heuristic; > 0: split keys until a launch has about this many waves */
+    int decode_chunk;         /* 0 = heuristic; > 0 (multiple of 64): keys per decode work item          */
+    int decode_work_item;     /* -1 = heuristic; 0 = one wave per work item; 1 = one workgroup            */
+    int decode_score_path;    /* -1 = heuristic; 0 = VALU scores for H_q/H_kv = 4, 8; 1 = MFMA scores     */
+    int decode_mfma_depth;    /* -1 = heuristic; 0 / 1 = tiles prefetched ahead in the MFMA-score kernel  */
+    int decode_single_launch; /* -1 = heuristic; 0 = separate merge launch; 1 = last-arriver merge        */
+    int prefill_split;        /* 0 = heuristic; > 0: forced number of key-range splits                    */
+} nv_tuning;
+NV_API int nv_set_tuning(const nv_tuning* t);   /* NULL restores the heuristics */
+NV_API int nv_get_tuning(nv_tuning* out);
+
+/*
  * KV-cache scatter.  Replaces Attention.store_kvcache, nanovllm/layers/attention.py:210-219:
  *   k_cache[slot // block_size, slot % block_size] = k[t]   (same for v)
  * k, v: [T, H_kv, D] bf16, token stride given in ELEMENTS (rows themselves contiguous).

@@ -11,15 +11,27 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnanovllm_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class Tuning(C.Structure):
+    """Mirror of `nv_tuning` (include/nanovllm_hip.h): launch-plan overrides, heuristics by default."""
+    _fields_ = [("decode_target_waves", _i32), ("decode_chunk", _i32), ("decode_work_item", _i32),
+                ("decode_score_path", _i32), ("decode_mfma_depth", _i32), ("decode_single_launch", _i32),
+                ("prefill_split", _i32)]
+    DEFAULTS = dict(decode_target_waves=0, decode_chunk=0, decode_work_item=-1, decode_score_path=-1,
+                    decode_mfma_depth=-1, decode_single_launch=-1, prefill_split=0)
+
 
 # name -> (restype, argtypes); must mirror include/nanovllm_hip.h exactly
 PROTOTYPES = {
     "nv_strerror": (C.c_char_p, [_i32]),
     "nv_last_error": (C.c_char_p, []),
     "nv_abi_version": (_i32, []),
+    "nv_set_tuning": (_i32, [C.POINTER(Tuning)]),
+    "nv_get_tuning": (_i32, [C.POINTER(Tuning)]),
     "nv_store_kvcache": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _i32, _i64, _i64, _vp]),
     "nv_attn_decode_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "nv_attn_decode_paged": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
@@ -77,3 +89,22 @@ def check(rc: int, what: str) -> None:
         raise NanoVllmHipError(
             f"{what}: {dll.nv_strerror(rc).decode()} ({rc}): {dll.nv_last_error().decode()}"
         )
+
+
+def set_tuning(**fields) -> None:
+    """Override launch-plan heuristics process-wide (`nv_set_tuning`); no arguments restores them.
+    Unknown field names raise.  A measurement / test aid: the product path never calls it."""
+    if not fields:
+        check(lib().nv_set_tuning(None), "nv_set_tuning")
+        return
+    unknown = set(fields) - set(Tuning.DEFAULTS)
+    if unknown:
+        raise ValueError(f"unknown tuning fields: {sorted(unknown)}")
+    t = Tuning(**{**Tuning.DEFAULTS, **fields})
+    check(lib().nv_set_tuning(C.byref(t)), "nv_set_tuning")
+
+
+def get_tuning() -> dict:
+    t = Tuning()
+    check(lib().nv_get_tuning(C.byref(t)), "nv_get_tuning")
+    return {name: getattr(t, name) for name, _ in Tuning._fields_}

@@ -20,7 +20,6 @@
 // including the one stored earlier in the same forward, :230-231).
 #include "nv_common.h"
 
-#include <stdlib.h>
 
 // Build-time tuning knobs (defaults are the measured best on MI355X).
 #ifndef NV_DEC_WAVES
@@ -642,28 +641,37 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
     *reinterpret_cast<uint2*>(o + 4 * d4) = w;
 }
 
-// Keys per work item.  Smaller chunks give more, finer-grained waves (better balance on
-// ragged batches, more loads in flight for small batches) at the price of more partials.
+// Launch plan of one call: which kernel, how the keys are cut into work items.  Computed from the
+// shapes and the process-wide overrides (nv_set_tuning) only, so nv_attn_decode_workspace_bytes and
+// the launch agree by construction.
+//
+// Keys per work item: smaller chunks give more, finer-grained waves (better balance on ragged
+// batches, more loads in flight for small batches) at the price of more partials.
 // G >= 4 runs the MFMA-score kernel (about 200 registers: one 4-wave workgroup per SIMD set and
 // CU at a time), which measured fastest with one workgroup per CU; the VALU kernel wants two.
-static bool decode_uses_mfma(int G) {
-    if (G == 3 || (G > 4 && G < 8)) return true;  // only the MFMA kernel takes a padded head count
-    const char* ve = getenv("NV_DECODE_VALU");  // 1 keeps G = 4, 8 on the all-VALU kernel: a comparison aid
-    return G >= 4 && !(ve && atoi(ve) > 0);
-}
-
 struct DecodePlan {
-    int chunk;   // keys per work item
-    int nsplit;  // work items per (sequence, kv head)
-    bool wgs;    // work item = workgroup (its waves split the chunk) instead of wave
+    int chunk;        // keys per work item
+    int nsplit;       // work items per (sequence, kv head)
+    bool wgs;         // work item = workgroup (its waves split the chunk) instead of wave
+    bool mfma;        // scores on the MFMA pipe (G >= 3)
+    bool mfma_deep;   // MFMA-score kernel: one tile of register prefetch
+    bool lean;        // VALU kernel: no register prefetch
 };
 
+static bool decode_uses_mfma(int G, const nv_tuning& tn) {
+    if (G == 3 || (G > 4 && G < 8)) return true;  // only the MFMA kernel takes a padded head count
+    if (tn.decode_score_path >= 0) return G >= 4 && tn.decode_score_path == 1;
+    return G >= 4;
+}
+
 static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
+    const nv_tuning tn = tuning();
     DecodePlan d;
+    d.mfma = decode_uses_mfma(G, tn);
     const long long bh = (long long)B * H_kv;
-    const char* te = getenv("NV_DECODE_TARGET_WAVES");  // tuning aid
-    const long long target = te && atoi(te) > 0 ? atoi(te)
-                             : (decode_uses_mfma(G) ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES);
+    const long long target = tn.decode_target_waves > 0
+                                 ? tn.decode_target_waves
+                                 : (d.mfma ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES);
     // Few (sequence, kv head) pairs: a workgroup per work item, 4 waves on its chunk, so the
     // launch reaches the target with a quarter of the partial states (often none at all).
     // Not when the waves would stream >= 1024 keys each anyway and the cache row holds >= 4 kv
@@ -671,13 +679,10 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
     // tokens (1 KiB contiguous per token) beat four waves on distant tokens (measured 6.2 vs
     // 5.7 TB/s at 8 sequences x 32 k keys).
     const long long wave_keys = max_k / ((target + bh - 1) / bh > 0 ? (target + bh - 1) / bh : 1);
-    const char* we = getenv("NV_DECODE_WGS");  // 0 / 1 forces the form: a tuning aid
-    d.wgs = we ? atoi(we) > 0 : (bh * 2 <= target && (H_kv <= 2 || wave_keys < 1024));
-    // NV_DECODE_CHUNK (multiple of 64) overrides the heuristic: a tuning aid
-    const char* e = getenv("NV_DECODE_CHUNK");
-    const int forced = e ? atoi(e) : 0;
-    if (forced > 0 && forced % 64 == 0) {
-        d.chunk = forced;
+    d.wgs = tn.decode_work_item >= 0 ? tn.decode_work_item == 1
+                                     : (bh * 2 <= target && (H_kv <= 2 || wave_keys < 1024));
+    if (tn.decode_chunk > 0) {
+        d.chunk = tn.decode_chunk;
     } else {
         // Fewest splits that still give the launch about `target` waves; unsplit sequences are
         // written directly (no partials, no merge launch).  Chunks are capped so that one long
@@ -693,6 +698,12 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
     }
     const int n = (max_k + d.chunk - 1) / d.chunk;
     d.nsplit = n < 1 ? 1 : n;
+    // Prefetch depth: one tile ahead hides HBM latency when each wave streams a long chunk
+    // and waves are scarce; with many resident waves (or G = 8, where registers are the
+    // limit) thread-level parallelism already covers it and the leaner kernel is faster.
+    d.lean = G >= 8 || (d.nsplit == 1 && bh >= NV_DEC_TARGET_WAVES);
+    // one tile of prefetch measured faster than none on every G >= 4 shape tried
+    d.mfma_deep = tn.decode_mfma_depth >= 0 ? tn.decode_mfma_depth == 1 : true;
     return d;
 }
 
@@ -763,15 +774,11 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
                    (long long)workspace_bytes, (long long)need);
     }
     const int64_t items = (int64_t)B * p.nsplit * H_kv;
-    const bool wgs = plan.wgs;
+    const bool wgs = plan.wgs, lean = plan.lean, use_mfma = plan.mfma, mfma_deep = plan.mfma_deep;
     NV_REQUIRE(items < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
     const unsigned grid = wgs ? (unsigned)items : (unsigned)((items + kDecWaves - 1) / kDecWaves);
     hipStream_t st = (hipStream_t)stream;
     const bool aligned = block_size % 16 == 0 && p.chunk % 64 == 0;
-    // Prefetch depth: one tile ahead hides HBM latency when each wave streams a long chunk
-    // and waves are scarce; with many resident waves (or G = 8, where registers are the
-    // limit) thread-level parallelism already covers it and the leaner kernel is faster.
-    const bool lean = G >= 8 || (p.nsplit == 1 && items >= NV_DEC_TARGET_WAVES);
 #define NV_DEC_LAUNCH2(GG, AL)                                                                      \
     do {                                                                                            \
         if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);       \
@@ -783,10 +790,6 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         if (aligned) NV_DEC_LAUNCH2(GG, true); \
         else NV_DEC_LAUNCH2(GG, false);      \
     } while (0)
-    const bool use_mfma = decode_uses_mfma(G);
-    // one tile of prefetch measured faster than none on every G >= 4 shape tried
-    const char* de = getenv("NV_DECODE_MFMA_DEPTH");  // tuning aid
-    const bool mfma_deep = de ? atoi(de) > 0 : true;
 #define NV_DEC_LAUNCH_M2(GG, AL)                                                                    \
     do {                                                                                            \
         if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \

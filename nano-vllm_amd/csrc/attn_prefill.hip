@@ -441,9 +441,9 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
     const int tiles = (max_seqlen_k + kBN - 1) / kBN;
     int ns = 1;
-    const char* se = getenv("NV_PREFILL_SPLIT");  // forces the split count: a tuning aid
-    if (se && atoi(se) > 0) {
-        ns = atoi(se);
+    const nv_tuning tn = tuning();
+    if (tn.prefill_split > 0) {
+        ns = tn.prefill_split;
     } else {
         const int64_t wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
         const int64_t target = 512;  // two workgroups per CU

@@ -5,6 +5,11 @@ namespace nv {
 
 static thread_local char g_err[512] = "";
 
+static const nv_tuning kDefaultTuning = {0, 0, -1, -1, -1, -1, 0};
+static nv_tuning g_tuning = kDefaultTuning;
+
+nv_tuning tuning() { return g_tuning; }
+
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -27,4 +32,24 @@ extern "C" const char* nv_strerror(int code) {
     }
 }
 
-extern "C" int nv_abi_version(void) { return 2; }
+extern "C" int nv_abi_version(void) { return 3; }
+
+extern "C" int nv_set_tuning(const nv_tuning* t) {
+    if (!t) {
+        nv::g_tuning = nv::kDefaultTuning;
+        return NV_OK;
+    }
+    NV_REQUIRE(t->decode_target_waves >= 0 && t->decode_chunk >= 0 && t->decode_chunk % 64 == 0 &&
+                   t->prefill_split >= 0 && t->decode_work_item >= -1 && t->decode_work_item <= 1 &&
+                   t->decode_score_path >= -1 && t->decode_score_path <= 1 && t->decode_mfma_depth >= -1 &&
+                   t->decode_mfma_depth <= 1 && t->decode_single_launch >= -1 && t->decode_single_launch <= 1,
+               NV_ERR_INVALID_ARG, "nv_set_tuning: field out of range");
+    nv::g_tuning = *t;
+    return NV_OK;
+}
+
+extern "C" int nv_get_tuning(nv_tuning* out) {
+    NV_REQUIRE(out, NV_ERR_INVALID_ARG, "nv_get_tuning: null pointer");
+    *out = nv::g_tuning;
+    return NV_OK;
+}

@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // ---- error reporting -------------------------------------------------------------
 void set_error(const char* fmt, ...);
+nv_tuning tuning();   // snapshot of the process-wide launch-plan overrides (nv_set_tuning)
 
 #define NV_REQUIRE(cond, code, ...)          \
     do {                                     \

@@ -24,6 +24,14 @@ def hip():
     return nanovllm_amd, ops
 
 
+@pytest.fixture
+def tuning():
+    """Force launch-plan choices through nv_set_tuning for one test; heuristics are restored after."""
+    from nanovllm_amd import _lib
+    yield _lib.set_tuning
+    _lib.set_tuning()
+
+
 def to_dev(p):
     return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in p.items()}
 
@@ -317,7 +325,7 @@ def test_decode_monotone_scores(hip, H_q, H_kv, direction):
 
 @pytest.mark.parametrize("form", ["0", "1"])
 @pytest.mark.parametrize("H_q,H_kv,bs", [(16, 8, 256), (32, 8, 256), (8, 1, 256), (4, 4, 48)])
-def test_decode_both_work_item_forms(hip, monkeypatch, form, H_q, H_kv, bs):
+def test_decode_both_work_item_forms(hip, tuning, form, H_q, H_kv, bs):
     """Work item = wave (0) or workgroup whose four waves split the chunk and merge in LDS (1), each
     forced, with and without a global split (long and short contexts, empty quarters, 48-token blocks)."""
     _, ops = hip
@@ -326,7 +334,7 @@ def test_decode_both_work_item_forms(hip, monkeypatch, form, H_q, H_kv, bs):
     p = make_paged_problem(H_q + bs, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb)
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
                                             p["block_tables"], p["scale"])
-    monkeypatch.setenv("NV_DECODE_WGS", form)
+    tuning(decode_work_item=int(form))
     _attn_check(_run_attention(ops, to_dev(p), "decode"), ref, f"decode-form{form}")
 
 
@@ -411,7 +419,7 @@ def test_prefill_key_range_split_long_chunk(hip):
 
 
 @pytest.mark.parametrize("nsplit", [2, 3, 7])
-def test_prefill_forced_key_range_split_ragged(hip, monkeypatch, nsplit):
+def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit):
     """Forced split counts on a ragged mixed batch: splits that lie wholly above a row block's
     diagonal are empty, sequences with one query stay with the decode kernel."""
     _, ops = hip
@@ -420,7 +428,7 @@ def test_prefill_forced_key_range_split_ragged(hip, monkeypatch, nsplit):
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
                                             p["block_tables"], p["scale"])
     pd = to_dev(p)
-    monkeypatch.setenv("NV_PREFILL_SPLIT", str(nsplit))
+    tuning(prefill_split=nsplit)
     _attn_check(_run_attention(ops, pd, "prefill"), ref, f"prefill-split{nsplit}")
     _attn_check(_run_attention(ops, pd, "mixed"), ref, f"mixed-split{nsplit}")
 

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--ctx-hi", type=int, default=768)
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
-    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup)")
+    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
@@ -48,22 +48,23 @@ def main():
     for rnd in range(args.rounds + 1):
         for name, dll in dlls.items():
           for mode in args.modes.split(","):
-            os.environ.pop("NV_DECODE_VALU", None)
-            os.environ.pop("NV_DECODE_MFMA_DEPTH", None)
-            os.environ.pop("NV_DECODE_WGS", None)
+            fields = {}
             if mode in ("wgs0", "wgs1"):
-                os.environ["NV_DECODE_WGS"] = mode[3]
+                fields["decode_work_item"] = int(mode[3])
             elif mode == "valu":
-                os.environ["NV_DECODE_VALU"] = "1"
+                fields["decode_score_path"] = 0
             elif mode.startswith("mfma"):
-                os.environ["NV_DECODE_MFMA_DEPTH"] = mode[4:]
+                fields["decode_mfma_depth"] = int(mode[4:])
+            elif mode in ("single0", "single1"):
+                fields["decode_single_launch"] = int(mode[6])
             for chunk in chunks:
-                os.environ.pop("NV_DECODE_CHUNK", None)
-                os.environ.pop("NV_DECODE_TARGET_WAVES", None)
+                f = dict(fields)
                 if chunk > 0:
-                    os.environ["NV_DECODE_CHUNK"] = str(chunk)
+                    f["decode_chunk"] = chunk
                 elif chunk < 0:
-                    os.environ["NV_DECODE_TARGET_WAVES"] = str(-chunk)
+                    f["decode_target_waves"] = -chunk
+                t = _lib.Tuning(**{**_lib.Tuning.DEFAULTS, **f})
+                assert dll.nv_set_tuning(t) == 0, dll.nv_last_error()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 for l in range(w.L):
@@ -83,9 +84,8 @@ def main():
         med, best = statistics.median(ts), min(ts)
         print(f"{name:>16s} chunk={chunk:4d}  median {med*1e3:8.2f} us  {nbytes/med/1e6:7.1f} GB/s   "
               f"best {best*1e3:8.2f} us {nbytes/best/1e6:7.1f} GB/s")
-    for k in ("NV_DECODE_CHUNK", "NV_DECODE_TARGET_WAVES", "NV_DECODE_VALU", "NV_DECODE_MFMA_DEPTH", "NV_DECODE_WGS"):
-        os.environ.pop(k, None)
-
+    for dll in dlls.values():
+        dll.nv_set_tuning(None)
 
 if __name__ == "__main__":
     main()
