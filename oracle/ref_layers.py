@@ -44,9 +44,43 @@ def rmsnorm_ref_eager(x: torch.Tensor, weight: torch.Tensor, eps: float, residua
     return (y, new_res) if residual is not None else y
 
 
-def build_cos_sin_cache(rotary_dim: int, max_seq_len: int, base: float) -> torch.Tensor:
-    """rope.py:31-43: fp32 [max_seq_len, 1, rotary_dim] = cos(pos x inv_freq) | sin(...)."""
+def llama3_inv_freq_ref(inv_freq: torch.Tensor, rope_scaling: dict) -> torch.Tensor:
+    """The published Llama-3.1 ("llama3" rope_type) frequency rule, one frequency at a time in fp32
+    scalars.  The reference refuses rope scaling (nanovllm/layers/rope.py:67 asserts
+    ``rope_scaling is None``), so there is nothing of its own to follow: this restates the rule of
+    the Llama-3.1 model card / Hugging Face ``rope_type="llama3"`` initialisation.  With
+    wavelength = 2*pi / f and L = original_max_position_embeddings:
+      wavelength > L / low_freq_factor   ->  f / factor            (long waves: slowed down)
+      wavelength < L / high_freq_factor  ->  f                     (short waves: unchanged)
+      otherwise                          ->  (1 - s) * f / factor + s * f,
+                                             s = (L / wavelength - low) / (high - low)
+    """
+    import numpy as np
+    f32 = np.float32
+    factor, low, high = (f32(rope_scaling[k]) for k in ("factor", "low_freq_factor", "high_freq_factor"))
+    L = f32(rope_scaling["original_max_position_embeddings"])
+    low_wavelen, high_wavelen = L / low, L / high
+    out = []
+    for f in inv_freq.numpy().astype(np.float32):
+        wavelen = f32(2 * np.pi) / f
+        if wavelen > low_wavelen:
+            out.append(f / factor)
+        elif wavelen < high_wavelen:
+            out.append(f)
+        else:
+            s = (L / wavelen - low) / (high - low)
+            out.append((f32(1) - s) * f / factor + s * f)
+    return torch.from_numpy(np.array(out, dtype=np.float32))
+
+
+def build_cos_sin_cache(rotary_dim: int, max_seq_len: int, base: float, rope_scaling: dict | None = None) -> torch.Tensor:
+    """rope.py:31-43: fp32 [max_seq_len, 1, rotary_dim] = cos(pos x inv_freq) | sin(...).
+    `rope_scaling` (not supported by the reference) rescales inv_freq by llama3_inv_freq_ref first."""
     inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.int64).to(torch.float) / rotary_dim))
+    if rope_scaling is not None:
+        kind = rope_scaling.get("rope_type", rope_scaling.get("type"))
+        assert kind == "llama3", f"oracle: rope_scaling type {kind!r} has no restatement"
+        inv_freq = llama3_inv_freq_ref(inv_freq, rope_scaling)
     pos = torch.arange(max_seq_len, dtype=torch.float)
     freqs = torch.einsum("i,j -> ij", pos, inv_freq)
     return torch.cat((freqs.cos(), freqs.sin()), dim=-1).unsqueeze(1)

@@ -50,8 +50,9 @@ class RMSNorm(nn.Module):
 class Rope(nn.Module):
     def __init__(self, head_size, max_position, base, rope_scaling=None):
         super().__init__()
-        assert rope_scaling is None, "the oracle follows the reference: no rope scaling"
-        self.register_buffer("cos_sin_cache", ref_layers.build_cos_sin_cache(head_size, max_position, base),
+        # rope_scaling: None as in the reference (rope.py:67), or a llama3 dict (oracle's own restatement)
+        self.register_buffer("cos_sin_cache",
+                             ref_layers.build_cos_sin_cache(head_size, max_position, base, rope_scaling),
                              persistent=False)
 
     def forward(self, positions, query, key):
@@ -67,7 +68,7 @@ _ropes: dict = {}
 
 
 def make_rope(head_size, max_position, base, rope_scaling=None):
-    key = (head_size, max_position, base)
+    key = (head_size, max_position, base, tuple(sorted(rope_scaling.items())) if rope_scaling else None)
     if key not in _ropes:
         _ropes[key] = Rope(head_size, max_position, base, rope_scaling)
     return _ropes[key]

@@ -18,7 +18,8 @@ Fixtures (bf16 tensors are stored as their int16 bit patterns):
   g2_rmsnorm.npz  RMSNorm.forward compiled, with/without residual, hidden and per-head (reference)
   g7_silu.npz     SiluAndMul.forward compiled (reference)
   g3_rope.npz     RotaryPositionEmbedding.forward                (reference output)
-  g4_attention.npz  paged varlen attention cases                 (oracle; cross-checked)
+  g4_attention.npz  paged varlen attention cases: the reference SDPA helper's output for every
+                    full-prefill / decode sequence, the oracle's for chunked ones (marked unpinned)
   g5_hash.json    BlockManager.compute_hash known answers        (reference output)
   g6_paging.json  scheduler / block-manager scenario trace       (reference, can_allocate patched)
 """
@@ -147,8 +148,9 @@ def g3_rope(ref):
              head_dim=np.int32(D), max_pos=np.int32(max_pos), base=np.float64(base))
 
 
-def _attention_case(g, name, n_qs, n_ks, H_q, H_kv, bs, NB, D=128):
-    """Random paged problem: non-monotone physical block ids, -1 padded tables."""
+def _attention_case(g, name, n_qs, n_ks, H_q, H_kv, bs, NB, D=128, coarse=False):
+    """Random paged problem: non-monotone physical block ids, -1 padded tables.  coarse=True draws the
+    cache from N(0,1) rounded to multiples of 1/8 (few distinct bf16 patterns: the fixture compresses)."""
     B = len(n_qs)
     perm = torch.randperm(NB, generator=g).tolist()
     width = max((n + bs - 1) // bs for n in n_ks) + 1           # at least one padding column
@@ -162,6 +164,9 @@ def _attention_case(g, name, n_qs, n_ks, H_q, H_kv, bs, NB, D=128):
     q = torch.randn(T, H_q, D, generator=g).bfloat16()
     k_cache = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
     v_cache = torch.randn(NB, bs, H_kv, D, generator=g).bfloat16()
+    if coarse:
+        k_cache = ((k_cache.float() * 8).round() / 8).bfloat16()
+        v_cache = ((v_cache.float() * 8).round() / 8).bfloat16()
     cu_q = torch.tensor([0] + np.cumsum(n_qs).tolist(), dtype=torch.int32)
     cu_k = torch.tensor([0] + np.cumsum(n_ks).tolist(), dtype=torch.int32)
     return dict(name=name, q=q, k_cache=k_cache, v_cache=v_cache, cu_q=cu_q, cu_k=cu_k,
@@ -169,6 +174,14 @@ def _attention_case(g, name, n_qs, n_ks, H_q, H_kv, bs, NB, D=128):
 
 
 def g4_attention(ref):
+    """Paged varlen attention cases.  `{name}_ref_pinned[b]` says where the rows of sequence b in
+    `{name}_out` come from:
+      True  -- from the REFERENCE's own dense helper Attention._scaled_dot_product_attention_batch
+               (nanovllm/layers/attention.py:273-335), run here on the gathered keys.  The helper is
+               valid for full prefill (n_q == n_k) and decode (n_q == 1) only: its top-left tril
+               mask is wrong for chunked prefill.  The oracle must reproduce these rows to 1e-5.
+      False -- from the oracle restatement (chunked prefill, 1 < n_q < n_k).  Nothing the reference
+               holds can pin these rows: they rest on flash-attn's published bottom-right rule."""
     from oracle.ref_attention import paged_attention_ref, gather_kv
     g = torch.Generator().manual_seed(404)
     cases = [
@@ -179,15 +192,22 @@ def g4_attention(ref):
         _attention_case(g, "decode_g8", [1, 1], [257, 31], 8, 1, 256, 3),
         _attention_case(g, "mixed_g2", [1, 40, 1, 3], [90, 40, 17, 67], 4, 2, 64, 8),
         _attention_case(g, "decode_g1", [1, 1, 1], [16, 33, 7], 2, 2, 64, 4),
+        # the reference's block size (256), full prefill and decode, 2 / 4 / 8 query heads per kv head
+        _attention_case(g, "bs256_full_prefill_g2", [258, 40], [258, 40], 2, 1, 256, 4, coarse=True),
+        _attention_case(g, "bs256_full_prefill_g4", [257, 33], [257, 33], 4, 1, 256, 4, coarse=True),
+        _attention_case(g, "bs256_full_prefill_g8", [258], [258], 8, 1, 256, 3, coarse=True),
+        _attention_case(g, "bs256_decode_g2", [1, 1, 1], [513, 256, 700], 2, 1, 256, 7, coarse=True),
+        _attention_case(g, "bs256_decode_g4", [1, 1, 1], [257, 768, 1], 4, 1, 256, 6, coarse=True),
+        _attention_case(g, "bs256_decode_g8", [1, 1], [600, 255], 8, 1, 256, 5, coarse=True),
+        _attention_case(g, "bs256_mixed_g4", [1, 200, 1, 70], [300, 200, 40, 326], 4, 1, 256, 7, coarse=True),
     ]
     out = {"names": np.array([c["name"] for c in cases])}
     for c in cases:
         o = paged_attention_ref(c["q"], c["k_cache"], c["v_cache"], c["cu_q"], c["cu_k"], c["block_tables"], c["scale"])
-        # cross-check against the reference's own dense SDPA helper (top-left causal mask:
-        # only valid for n_q == n_k and n_q == 1), sequence by sequence
         attn = ref["Attention"](c["H_q"], 128, c["H_kv"], c["scale"], 4096)
         cq, ck = c["cu_q"].tolist(), c["cu_k"].tolist()
-        checked = 0
+        expected = o.clone()
+        pinned = np.zeros(len(cq) - 1, dtype=np.bool_)
         for b in range(len(cq) - 1):
             n_q, n_k = cq[b + 1] - cq[b], ck[b + 1] - ck[b]
             if n_q == n_k or n_q == 1:
@@ -197,13 +217,14 @@ def g4_attention(ref):
                 r = attn._scaled_dot_product_attention_batch(qb, kb, vb)[0]
                 err = (r - o[cq[b]:cq[b + 1]]).abs().max().item()
                 assert err < 1e-5, (c["name"], b, err)
-                checked += 1
-        print(f"  g4[{c['name']}]: {checked}/{len(cq) - 1} sequences cross-checked against the reference SDPA helper")
+                expected[cq[b]:cq[b + 1]] = r
+                pinned[b] = True
+        print(f"  g4[{c['name']}]: {int(pinned.sum())}/{len(cq) - 1} sequences carry the reference SDPA helper's output")
         n = c["name"]
         out.update({f"{n}_q": bits(c["q"]), f"{n}_k_cache": bits(c["k_cache"]), f"{n}_v_cache": bits(c["v_cache"]),
                     f"{n}_cu_q": c["cu_q"].numpy(), f"{n}_cu_k": c["cu_k"].numpy(),
                     f"{n}_block_tables": c["block_tables"].numpy(), f"{n}_scale": np.float32(c["scale"]),
-                    f"{n}_out": o.numpy()})
+                    f"{n}_out": expected.numpy(), f"{n}_ref_pinned": pinned})
     np.savez_compressed(os.path.join(HERE, "g4_attention.npz"), **out)
 
 

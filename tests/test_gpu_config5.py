@@ -1,0 +1,151 @@
+"""GPU: BASELINE config 5 (Llama-3.1-8B shapes: 32 query / 8 kv heads x 128, no q/k-norm, llama3-scaled
+rotary table, contexts of 32768 tokens = 128 cache blocks per sequence) through the C ABI.
+
+The reference cannot run this model (nanovllm/layers/rope.py:67 asserts ``rope_scaling is None``), so the
+oracle's llama3 rule is its own restatement of the published formula (oracle/ref_layers.py, pinned on the
+CPU in tests/test_oracle_golden.py).  Bars as everywhere: rotary outputs and the KV scatter bit-exact,
+attention max-abs <= 2e-2 against the fp32 oracle.
+"""
+import pytest
+import torch
+
+from conftest import bits
+from oracle import ref_attention, ref_layers, ref_modules
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-2
+LLAMA3 = dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0, high_freq_factor=4.0,
+              original_max_position_embeddings=8192)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from nanovllm_amd import _lib, ops
+    _lib.lib()
+    return ops
+
+
+@pytest.fixture(scope="module")
+def long_cache():
+    """8 sequences x 32768 keys, H_kv 8, block 256: 1024 shuffled physical blocks (537 MB each for K, V)."""
+    B, n_k, H_kv, D, bs = 8, 32768, 8, 128, 256
+    per = n_k // bs
+    NB = B * per
+    gen = torch.Generator(device=DEV).manual_seed(55)
+    k = torch.randn(NB, bs, H_kv, D, generator=gen, device=DEV, dtype=torch.float32).bfloat16()
+    v = torch.randn(NB, bs, H_kv, D, generator=gen, device=DEV, dtype=torch.float32).bfloat16()
+    g = torch.Generator().manual_seed(56)
+    bt = torch.randperm(NB, generator=g).view(B, per).to(torch.int32)
+    q = torch.randn(B, 32, D, generator=g).bfloat16()
+    return dict(k=k, v=v, bt=bt, q=q, n_k=n_k, bs=bs, per=per, NB=NB)
+
+
+def _oracle_row(c, b, hq, n_k, G=4):
+    """fp32 oracle output of (sequence b, query head hq): the oracle run on that head's slice of the cache."""
+    hkv = hq // G
+    rows = c["bt"][b].long()
+    kc = c["k"][:, :, hkv:hkv + 1].cpu()
+    vc = c["v"][:, :, hkv:hkv + 1].cpu()
+    return ref_attention.paged_attention_ref(c["q"][b:b + 1, hq:hq + 1], kc, vc, torch.tensor([0, 1], dtype=torch.int32),
+                                             torch.tensor([0, n_k], dtype=torch.int32), rows[None].to(torch.int32),
+                                             128 ** -0.5)[0, 0]
+
+
+@pytest.mark.parametrize("B", [1, 4, 8])
+def test_config5_decode_32k_context(ops, long_cache, B):
+    """ctx 32768, H 32/8, B sequences per replica: sampled (sequence, head) rows against the oracle,
+    V == const gives const, and a permutation of the physical blocks leaves the output bit-identical.
+    B = 1 and B = 4 cut every (sequence, kv head) into 32 key chunks (workgroup and wave work items
+    respectively) and combine them with the 8-group merge; B = 8 uses 16 chunks."""
+    from nanovllm_amd import _lib
+    c = long_cache
+    n_k, per = c["n_k"], c["per"]
+    ns = _lib.lib().nv_attn_decode_workspace_bytes(B, 32, 8, 128, n_k) // (B * 32 * 132 * 4)
+    assert ns == (16 if B == 8 else 32), ns
+    lens = [n_k - 255 * i for i in range(B)]                       # ragged tails inside the last blocks
+    cu_k = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=DEV)
+    bt = c["bt"][:B].to(DEV)
+    q = c["q"][:B].to(DEV)
+    o = ops.attn_decode_paged(q, c["k"], c["v"], cu_k, bt, n_k, 128 ** -0.5)
+    for b, hq in {(0, 0), (B - 1, 31), (B // 2, 13)}:
+        ref = _oracle_row(c, b, hq, lens[b])
+        err = (o[b, hq].float().cpu() - ref).abs().max().item()
+        assert err <= TOL, (B, b, hq, err)
+    const = torch.full_like(c["v"], 0.625)
+    oc = ops.attn_decode_paged(q, c["k"], const, cu_k, bt, n_k, 128 ** -0.5)
+    del const
+    assert (oc.float() - 0.625).abs().max().item() <= 4e-3
+    g = torch.Generator().manual_seed(B)
+    perm = torch.randperm(c["NB"], generator=g)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(c["NB"])
+    k2 = c["k"][perm.to(DEV)]
+    v2 = c["v"][perm.to(DEV)]
+    bt2 = inv[c["bt"][:B].long()].to(torch.int32).to(DEV)
+    o2 = ops.attn_decode_paged(q, k2, v2, cu_k, bt2, n_k, 128 ** -0.5)
+    assert torch.equal(o, o2)
+
+
+def test_llama3_rotary_bit_exact_up_to_position_131071(ops):
+    """nv_rope and the fused kernel without q/k-norm weights on the llama3-scaled table: bit-exact
+    against the oracle at positions across the whole 131072-entry table."""
+    D, max_pos, T, H_q, H_kv = 128, 131072, 96, 32, 8
+    table = ref_layers.build_cos_sin_cache(D, max_pos, 5e5, LLAMA3)
+    g = torch.Generator().manual_seed(31)
+    pos = torch.cat([torch.tensor([0, 1, 8191, 8192, 32767, 32768, 65535, 131070, 131071]),
+                     torch.randint(0, max_pos, (T - 9,), generator=g)]).to(torch.int64)
+    q = torch.randn(T, H_q, D, generator=g).bfloat16()
+    k = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    v = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    rq, rk = ref_layers.rope_ref(pos, q, k, table)
+    td = table.to(DEV)
+    qo, ko = ops.rope(pos.to(DEV), q.to(DEV), k.to(DEV), td)
+    assert torch.equal(bits(qo.cpu()), bits(rq)) and torch.equal(bits(ko.cpu()), bits(rk))
+    NB, bs = 2, 256
+    slots = torch.randperm(NB * bs, generator=g)[:T].to(torch.int32)
+    kc = torch.zeros(NB, bs, H_kv, D, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    ref_attention.store_kvcache_ref(rk, v, kc_ref, vc_ref, slots, bs)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    qo2, ko2 = ops.qknorm_rope_store(pos.to(DEV), q.to(DEV), k.to(DEV), v.to(DEV), None, None, td, 1e-5,
+                                     slots.to(DEV), kcd, vcd)
+    assert torch.equal(bits(qo2.cpu()), bits(rq)) and torch.equal(bits(ko2.cpu()), bits(rk))
+    assert torch.equal(bits(kcd.cpu()), bits(kc_ref)) and torch.equal(bits(vcd.cpu()), bits(vc_ref))
+
+
+def test_llama_shaped_engine_greedy_parity():
+    """Llama-3.1-style model on the path (no q/k-norm, llama3-scaled rotary table, 4 query heads per kv
+    head), one prompt longer than the 8192 original positions: the HIP engine runs free, the engine built
+    from the oracle's modules is teacher-forced on its tokens; logits agree within 2e-2 at every step
+    and a token may differ only inside a numerical tie."""
+    from test_gpu_engine import _drive, build
+    from nanovllm_amd.engine.llm_engine import LLMEngine
+    from nanovllm_amd.model.qwen3 import ModelConfig
+    cfg = ModelConfig(vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                      num_attention_heads=16, num_key_value_heads=4, head_dim=128, max_position_embeddings=16384,
+                      rms_norm_eps=1e-5, rope_theta=5e5, qk_norm=False, rope_scaling=dict(LLAMA3))
+    g = torch.Generator().manual_seed(2)
+    prompts = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in (16, 8300, 502)]
+    hip_model = build(cfg, None, True, seed=7)
+    ref_model = build(cfg, ref_modules, False, seed=7)
+    ref_model.load_state_dict(hip_model.state_dict())
+    assert not hasattr(hip_model.model.layers[0].self_attn, "q_norm")
+    kw = dict(block_size=256, num_kvcache_blocks=44, max_num_batched_tokens=1024, long_prefill_token_threshold=512,
+              device=DEV, eos=-1)
+    steps = 48
+    hip_trace = _drive(LLMEngine(hip_model, cfg, **kw), prompts, steps)
+    hip_tokens = [[t for t, _ in tr] for tr in hip_trace]
+    ref_trace = _drive(LLMEngine(ref_model, cfg, **kw), prompts, steps, forced=hip_tokens)
+    assert all(len(t) == steps for t in hip_tokens)
+    ties = 0
+    for tr_h, tr_r in zip(hip_trace, ref_trace):
+        for (tok, lg_h), (_, lg_r) in zip(tr_h, tr_r):
+            scale = max(1.0, lg_r.abs().max().item())
+            assert (lg_h - lg_r).abs().max().item() <= 2e-2 * scale
+            if tok != int(lg_r.argmax()):
+                ties += 1
+                assert (lg_r.max() - lg_r[tok]).item() <= 2e-2 * scale, "token differs outside a numerical tie"
+    assert ties <= 4, f"{ties} of {3 * steps} greedy tokens fell on numerical ties"

@@ -254,6 +254,9 @@ def _run_attention(ops, p, mode):
 
 
 def test_attention_golden_cases(hip, golden):
+    """HIP against the stored expectations of g4 directly: for full-prefill and decode sequences those
+    are the outputs of the reference's own dense SDPA helper (nanovllm/layers/attention.py:273-335),
+    for chunked-prefill sequences the oracle's (unpinned by the reference; see the fixture's mask)."""
     _, ops = hip
     g = golden("g4_attention.npz")
     for name in g["names"]:
