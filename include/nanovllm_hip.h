@@ -104,6 +104,27 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * nv_attn_decode_paged without a workspace argument, for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
+ * counterpart in the reference.  Same arguments, kernels and results as nv_attn_decode_paged; the
+ * split-key partial states go to an array built into the library's code object (32 MiB of device
+ * memory per GPU the library runs on, held until the process ends).  The call allocates nothing.
+ * A launch whose partial states need more than nv_attn_decode_static_scratch_bytes() is refused with
+ * NV_ERR_WORKSPACE (use nv_attn_decode_paged with a caller workspace then).  Every call on a GPU
+ * shares that GPU's array: calls that overlap in time on one GPU (different streams) race; calls on
+ * one stream are ordered and safe.  nv_attn_decode_static_scratch_bytes() returns the capacity and
+ * resolves the array's address on the current device (-1 on failure); calling it once per device
+ * before a graph capture keeps that lookup out of the capture.
+ */
+NV_API int64_t nv_attn_decode_static_scratch_bytes(void);
+NV_API int nv_attn_decode_paged_static(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                const int32_t* block_tables, int B, int max_blocks,
+                                int max_seqlen_k, int H_q, int H_kv, int D,
+                                int64_t num_blocks, int block_size, float scale,
+                                int64_t q_stride_t, int64_t o_stride_t, void* stream);
+
+/*
  * Varlen prefill / chunked-prefill attention over the paged cache, causal mask aligned
  * to the bottom-right corner: query i of n_q sees keys j <= n_k - n_q + i.
  * Replaces the same call (nanovllm/layers/attention.py:241-252) for steps with any

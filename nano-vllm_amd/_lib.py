@@ -36,6 +36,9 @@ PROTOTYPES = {
     "nv_attn_decode_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "nv_attn_decode_paged": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                     _i32, _i64, _i32, _f32, _i64, _i64, _vp, _i64, _vp]),
+    "nv_attn_decode_static_scratch_bytes": (_i64, []),
+    "nv_attn_decode_paged_static": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
+                                           _i32, _i64, _i32, _f32, _i64, _i64, _vp]),
     "nv_attn_prefill_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "nv_attn_prefill_varlen": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                       _i32, _i32, _i64, _i32, _f32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),

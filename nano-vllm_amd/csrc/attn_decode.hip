@@ -717,14 +717,13 @@ extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int 
     return (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
 }
 
-extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const void* v_cache, void* o,
-                                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
-                                    const int32_t* block_tables, int B, int max_blocks,
-                                    int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
-                                    int block_size, float scale, int64_t q_stride_t,
-                                    int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
-                                    void* stream) {
-    using namespace nv;
+namespace nv {
+static int decode_launch(const void* q, const void* k_cache, const void* v_cache, void* o,
+                         const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                         const int32_t* block_tables, int B, int max_blocks, int max_seqlen_k, int H_q,
+                         int H_kv, int D, int64_t num_blocks, int block_size, float scale,
+                         int64_t q_stride_t, int64_t o_stride_t, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
                    num_blocks > 0 && block_size > 0,
                NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
@@ -832,4 +831,71 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
         rc = check_launch("nv_attn_decode_paged(merge)");
     }
     return rc;
+}
+
+// ---- the allocation-free entry point's scratch ---------------------------------------------
+// One array per GPU, part of the code object, alive until the process ends.  In host code the
+// array's name is only a handle: its device address on the current GPU comes from
+// hipGetSymbolAddress and is kept per device.
+constexpr int64_t kStaticScratchBytes = 32ll << 20;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static void* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on the current device (looked up once per device).
+static int static_scratch_ptr(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    NV_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, NV_ERR_LAUNCH,
+               "nv_attn_decode_paged_static: hipGetDevice failed or device index %d out of range", dev);
+    void* ptr = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!ptr) {
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        NV_REQUIRE(e == hipSuccess && ptr, NV_ERR_LAUNCH,
+                   "nv_attn_decode_paged_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+        __atomic_store_n(&g_scratch_ptr[dev], ptr, __ATOMIC_RELEASE);
+    }
+    *out = ptr;
+    return NV_OK;
+}
+}  // namespace nv
+
+extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                    const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                    const int32_t* block_tables, int B, int max_blocks,
+                                    int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
+                                    int block_size, float scale, int64_t q_stride_t,
+                                    int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+    return nv::decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
+                             max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t,
+                             workspace, workspace_bytes, stream);
+}
+
+extern "C" int64_t nv_attn_decode_static_scratch_bytes(void) {
+    void* ptr = nullptr;
+    if (nv::static_scratch_ptr(&ptr) != NV_OK) return -1;
+    return nv::kStaticScratchBytes;
+}
+
+extern "C" int nv_attn_decode_paged_static(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                           const int32_t* block_tables, int B, int max_blocks,
+                                           int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
+                                           int block_size, float scale, int64_t q_stride_t,
+                                           int64_t o_stride_t, void* stream) {
+    using namespace nv;
+    const int64_t need = nv_attn_decode_workspace_bytes(B, H_q, H_kv, D, max_seqlen_k);
+    NV_REQUIRE(need <= kStaticScratchBytes, NV_ERR_WORKSPACE,
+               "nv_attn_decode_paged_static: this launch needs %lld bytes of split-key partial states, the "
+               "built-in scratch holds %lld; use nv_attn_decode_paged with a caller workspace",
+               (long long)need, (long long)kStaticScratchBytes);
+    void* ptr = nullptr;
+    const int rc = static_scratch_ptr(&ptr);
+    if (rc != NV_OK) return rc;
+    // Nothing in the scratch has to start at zero: every partial state the merge reads is written by
+    // this call's attention kernel first.
+    return decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
+                         max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t, ptr,
+                         kStaticScratchBytes, stream);
 }

@@ -18,6 +18,7 @@ int main(int argc, char** argv) {
     BIND(nv_strerror) BIND(nv_last_error) BIND(nv_abi_version) BIND(nv_store_kvcache)
     BIND(nv_set_tuning) BIND(nv_get_tuning)
     BIND(nv_attn_decode_workspace_bytes) BIND(nv_attn_decode_paged)
+    BIND(nv_attn_decode_static_scratch_bytes) BIND(nv_attn_decode_paged_static)
     BIND(nv_attn_prefill_workspace_bytes) BIND(nv_attn_prefill_varlen)
     BIND(nv_rmsnorm) BIND(nv_add_rmsnorm) BIND(nv_silu_and_mul) BIND(nv_rope) BIND(nv_qknorm_rope_store)
     if (p_nv_abi_version() < 3) { printf("abi %d\n", p_nv_abi_version()); return 3; }

@@ -1,0 +1,75 @@
+"""GPU: the allocation-free decode entry point (nv_attn_decode_paged_static, split-key partial states in
+a device array built into the library) against nv_attn_decode_paged with a caller workspace: the same
+kernels on the same plan, so the outputs must be bit-identical.  Two calls in a row, the second on a
+smaller input, so that stale partial states of the first call would show."""
+import pytest
+import torch
+
+from conftest import make_paged_problem
+from oracle import ref_attention
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _both(dll, p, H_q, H_kv, bs):
+    stream = torch.cuda.current_stream().cuda_stream
+    B = p["cu_k"].numel() - 1
+    nb = p["k_cache"].shape[0]
+    common = (p["q"].data_ptr(), p["k_cache"].data_ptr(), p["v_cache"].data_ptr())
+    meta = (p["cu_q"].data_ptr(), p["cu_k"].data_ptr(), p["block_tables"].data_ptr(), B, p["block_tables"].shape[1],
+            p["max_k"], H_q, H_kv, 128, nb, bs, p["scale"], p["q"].stride(0))
+    need = dll.nv_attn_decode_workspace_bytes(B, H_q, H_kv, 128, p["max_k"])
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=DEV)
+    o_ws = torch.full_like(p["q"], float("nan"))
+    o_st = torch.full_like(p["q"], float("nan"))
+    rc = dll.nv_attn_decode_paged(*common, o_ws.data_ptr(), *meta, o_ws.stride(0), ws.data_ptr(), ws.numel(), stream)
+    assert rc == 0, dll.nv_last_error()
+    before = torch.cuda.memory_allocated()
+    rc = dll.nv_attn_decode_paged_static(*common, o_st.data_ptr(), *meta, o_st.stride(0), stream)
+    assert rc == 0, dll.nv_last_error()
+    assert torch.cuda.memory_allocated() == before
+    torch.cuda.synchronize()
+    return o_ws, o_st, need
+
+
+def test_static_scratch_entry_point_matches_workspace_entry_point():
+    assert torch.cuda.is_available()
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    cap = dll.nv_attn_decode_static_scratch_bytes()
+    assert cap == 32 << 20
+    H_q, H_kv, bs = 32, 8, 256
+    # first call: long contexts, many key chunks per (sequence, kv head); second: fewer, shorter sequences
+    for seed, n_ks in ((1, [5000, 8192, 300, 4097]), (2, [2049, 700])):
+        nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+        p = make_paged_problem(seed, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb, device=DEV)
+        o_ws, o_st, need = _both(dll, p, H_q, H_kv, bs)
+        assert 16 < need <= cap                                   # the split path (scratch in use)
+        assert torch.equal(o_ws.view(torch.int16), o_st.view(torch.int16))
+        ref = ref_attention.paged_attention_ref(p["q"].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(), p["cu_q"].cpu(),
+                                                p["cu_k"].cpu(), p["block_tables"].cpu(), p["scale"])
+        assert (o_st.float().cpu() - ref).abs().max().item() <= 2e-2
+    # an unsplit launch needs no scratch and still runs
+    p = make_paged_problem(3, [1] * 300, [70] * 300, 16, 8, bs, 301, device=DEV)
+    o_ws, o_st, need = _both(dll, p, 16, 8, bs)
+    assert need == 16 and torch.equal(o_ws.view(torch.int16), o_st.view(torch.int16))
+
+
+def test_static_scratch_entry_point_refuses_oversized_launches():
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    _lib.set_tuning(decode_chunk=64, decode_work_item=0)          # 64-key chunks: a huge partial-state footprint
+    try:
+        B, H_q, H_kv, n_k = 64, 32, 8, 16384
+        assert dll.nv_attn_decode_workspace_bytes(B, H_q, H_kv, 128, n_k) > dll.nv_attn_decode_static_scratch_bytes()
+        x = torch.zeros(B, H_q, 128, dtype=torch.bfloat16, device=DEV)
+        kc = torch.zeros(1, 256, H_kv, 128, dtype=torch.bfloat16, device=DEV)
+        cu = torch.arange(B + 1, dtype=torch.int32, device=DEV)
+        bt = torch.zeros(B, 64, dtype=torch.int32, device=DEV)
+        rc = dll.nv_attn_decode_paged_static(x.data_ptr(), kc.data_ptr(), kc.data_ptr(), x.data_ptr(), cu.data_ptr(),
+                                             cu.data_ptr(), bt.data_ptr(), B, 64, n_k, H_q, H_kv, 128, 1, 256, 0.1,
+                                             x.stride(0), x.stride(0), torch.cuda.current_stream().cuda_stream)
+        assert rc == -3 and b"built-in scratch" in dll.nv_last_error()
+    finally:
+        _lib.set_tuning()
