@@ -41,6 +41,11 @@ class GenerationMetrics:
         }
 
 
+def _is_decode_row(s: Sequence) -> bool:
+    """One scheduled token that continues generated text (not a prompt chunk, not a recomputation)."""
+    return bool(s.output_tokens) and s.num_scheduled_tokens == 1 and s.completes_step
+
+
 class LLMEngine:
     def __init__(self, model: torch.nn.Module, cfg, block_size: int = 256, num_kvcache_blocks: int | None = None,
                  max_num_batched_tokens: int = 4000, long_prefill_token_threshold: int = 512,
@@ -67,6 +72,17 @@ class LLMEngine:
         if not prompt:
             raise ValueError("empty prompt")
         seq = Sequence(prompt, sampling_params)
+        # positions beyond the rotary table would be clamped by the kernels, and a request larger than the
+        # whole cache could never be scheduled: refuse both here
+        total = len(seq.prompt_tokens) + seq.sampling_params.max_tokens
+        max_pos = getattr(self.runner.cfg, "max_position_embeddings", None)
+        if max_pos is not None and total > max_pos:
+            raise ValueError(f"prompt ({len(seq.prompt_tokens)}) + max_tokens ({seq.sampling_params.max_tokens}) "
+                             f"exceeds max_position_embeddings ({max_pos})")
+        bs = self.scheduler.block_size
+        if -(-total // bs) > self.runner.num_kvcache_blocks:
+            raise ValueError(f"request needs {-(-total // bs)} KV-cache blocks, the cache has "
+                             f"{self.runner.num_kvcache_blocks}")
         self.scheduler.add(seq)
         return seq
 
@@ -79,7 +95,7 @@ class LLMEngine:
         seqs, _ = self.scheduler.schedule()
         if not seqs:
             raise ValueError("no sequences are scheduled")
-        decode_only = all(not s.is_prefill for s in seqs)
+        decode_only = all(_is_decode_row(s) for s in seqs)
         tokens = self.runner.run(seqs)
         finished = self.scheduler.update_from_output(seqs, tokens)
         return seqs, tokens, finished, decode_only
@@ -98,7 +114,7 @@ class LLMEngine:
         while not self.is_finished() or inflight is not None:
             t0 = time.perf_counter()
             batch = self.scheduler.schedule()[0] if not self.is_finished() else []
-            if self.pipelined_decode and batch and all(not s.is_prefill and s.num_scheduled_tokens == 1 for s in batch):
+            if self.pipelined_decode and batch and all(_is_decode_row(s) for s in batch):
                 handle = self.runner.launch_decode(batch, inflight[1] if inflight else None)
                 if inflight is not None:     # read step t while step t+1 runs
                     self.scheduler.resolve_pending(inflight[0], self.runner.fetch_tokens(inflight[1]))
@@ -106,6 +122,7 @@ class LLMEngine:
                 inflight = (batch, handle)
                 metrics.step_times.append((time.perf_counter() - t0, len(batch), True))
                 continue
+            waited = inflight
             if inflight is not None:         # a step with prompt rows needs the token values on the host
                 self.scheduler.resolve_pending(inflight[0], self.runner.fetch_tokens(inflight[1]))
                 inflight = None
@@ -115,8 +132,12 @@ class LLMEngine:
                         s.num_scheduled_tokens = 0
                 batch = kept
             if not batch:
+                if waited is None and not self.is_finished():
+                    # nothing in flight, nothing schedulable, requests left: cannot make progress
+                    raise RuntimeError("scheduler made no progress: the KV cache cannot hold the next chunk of any "
+                                       "request (num_kvcache_blocks too small for the admitted requests)")
                 continue
-            decode_only = all(not s.is_prefill for s in batch)
+            decode_only = all(_is_decode_row(s) for s in batch)
             tokens = self.runner.run(batch)
             self.scheduler.update_from_output(batch, tokens)
             if cuda:

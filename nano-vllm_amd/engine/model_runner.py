@@ -3,7 +3,9 @@
 Metadata integers follow the reference's ModelRunner._prepare_inputs / _prepare_block_tables /
 get_slot_mapping exactly (nanovllm/engine/model_runner.py:39-148): prefill rows take
 prompt[computed : computed+scheduled] at positions computed..; decode rows take the last sampled
-token at position num_tokens-1 with the slot of logical position `num_computed`; slot =
+token at position num_tokens-1 with the slot of logical position `num_computed` (both are the slice
+[computed, computed+scheduled) of prompt + outputs, which also covers the recomputation of a
+preempted sequence); slot =
 block_table[p // bs] * bs + p % bs; seqlen_q = scheduled, seqlen_k = computed + scheduled; block
 tables are right-padded with -1.  They are built with numpy in one pass (the reference loops per
 token and round-trips through the device, model_runner.py:140-148).  The cache has the reference's
@@ -47,7 +49,7 @@ def _prepare_decode_inputs(seqs: list[Sequence], block_size: int) -> dict:
 
 def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool = True) -> dict:
     """Pure host part: python ints / numpy arrays for one step (see module docstring)."""
-    if decode_fast_path and all(s.num_scheduled_tokens == 1 and not s.is_prefill for s in seqs):
+    if decode_fast_path and all(s.num_scheduled_tokens == 1 and s.output_tokens and s.completes_step for s in seqs):
         return _prepare_decode_inputs(seqs, block_size)
     ids, pos, slots = [], [], []
     n_q = np.empty(len(seqs), dtype=np.int64)
@@ -58,16 +60,21 @@ def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool
     for i, seq in enumerate(seqs):
         table = np.asarray(seq.block_table, dtype=np.int64)
         tables[i, :len(table)] = table
+        # tokens [start, end) of prompt + outputs: a prompt chunk, the last sampled token (decode:
+        # start = num_tokens - 1, which is the reference's position and slot for that row), or a
+        # chunk of a preempted sequence's recomputation
         start = seq.num_computed_tokens
-        if seq.is_prefill:
-            end = start + seq.num_scheduled_tokens
-            p = np.arange(start, end, dtype=np.int64)
-            ids.append(np.asarray(seq.prompt_tokens[start:end], dtype=np.int64))
-            pos.append(p)
+        end = start + seq.num_scheduled_tokens
+        n_prompt = len(seq.prompt_tokens)
+        if end <= n_prompt:
+            toks = seq.prompt_tokens[start:end]
+        elif start >= n_prompt:
+            toks = seq.output_tokens[start - n_prompt:end - n_prompt]
         else:
-            p = np.array([start], dtype=np.int64)                 # slot of logical position `computed`
-            ids.append(np.array([seq.output_tokens[-1]], dtype=np.int64))
-            pos.append(np.array([len(seq) - 1], dtype=np.int64))
+            toks = seq.prompt_tokens[start:] + seq.output_tokens[:end - n_prompt]
+        p = np.arange(start, end, dtype=np.int64)
+        ids.append(np.asarray(toks, dtype=np.int64))
+        pos.append(p)
         slots.append(table[p // block_size] * block_size + p % block_size)
         n_q[i] = seq.num_scheduled_tokens
         n_k[i] = seq.num_computed_tokens + seq.num_scheduled_tokens
@@ -101,7 +108,12 @@ class _DecodeGraph:
         o_bt = sec(batch * width, 4, o_cuk[2])
         o_src = sec(batch, 8, o_bt[2])      # pipelined decode: row of the previous step's tokens, or -1
         self._dev_buf = torch.zeros(o_src[2], dtype=torch.uint8, device=dev)
-        self._host_buf = torch.zeros(o_src[2], dtype=torch.uint8, pin_memory=dev.type == "cuda")
+        # Two pinned host mirrors used alternately, each guarded by an event recorded after its
+        # host-to-device copy: with pipelined decode the host runs ahead of the device, and a mirror
+        # must not be rewritten while an earlier step's asynchronous copy may still be reading it.
+        self._host_bufs = [torch.zeros(o_src[2], dtype=torch.uint8, pin_memory=dev.type == "cuda") for _ in range(2)]
+        self._copied = [None, None]
+        self._turn = 0
 
         def views(buf):
             return (buf[o_ids[0]:o_ids[1]].view(torch.int64), buf[o_pos[0]:o_pos[1]].view(torch.int64),
@@ -110,11 +122,12 @@ class _DecodeGraph:
                     buf[o_src[0]:o_src[1]].view(torch.int64))
         (self.input_ids, self.positions, self.slot_mapping, self.cu_seqlens_k, self.block_tables,
          self.src_rows) = views(self._dev_buf)
-        self._h = [t.numpy() for t in views(self._host_buf)]
-        self._h[5].fill(-1)
-        self._h[2].fill(-1)
-        self._h[4].fill(-1)
-        self._dev_buf.copy_(self._host_buf)
+        self._hs = [[t.numpy() for t in views(buf)] for buf in self._host_bufs]
+        for h in self._hs:
+            h[5].fill(-1)
+            h[2].fill(-1)
+            h[4].fill(-1)
+        self._dev_buf.copy_(self._host_bufs[0])
         self.cu_seqlens_q = torch.arange(batch + 1, dtype=torch.int32, device=dev)
         self.ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self.slot_mapping,
                                 cu_seqlens_q=self.cu_seqlens_q, cu_seqlens_k=self.cu_seqlens_k, max_seqlen_q=1,
@@ -136,7 +149,12 @@ class _DecodeGraph:
         """src_rows / prev_tokens (pipelined decode): row i takes its input token from
         prev_tokens[src_rows[i]] (still on the device) where src_rows[i] >= 0."""
         n = len(m["input_ids"])
-        h_ids, h_pos, h_slot, h_cuk, h_bt, h_src = self._h
+        turn = self._turn
+        self._turn ^= 1
+        if self._copied[turn] is not None:
+            self._copied[turn].synchronize()       # the copy that last read this mirror is done
+        h_ids, h_pos, h_slot, h_cuk, h_bt, h_src = self._hs[turn]
+        h_src[:] = -1
         if src_rows is not None:
             h_src[:n] = src_rows
         h_ids[:n] = m["input_ids"]
@@ -149,7 +167,11 @@ class _DecodeGraph:
         h_bt[:n, :bt.shape[1]] = bt
         h_bt[:n, bt.shape[1]:] = -1
         h_bt[n:] = -1
-        self._dev_buf.copy_(self._host_buf, non_blocking=True)
+        self._dev_buf.copy_(self._host_bufs[turn], non_blocking=True)
+        if self._dev_buf.is_cuda:
+            if self._copied[turn] is None:
+                self._copied[turn] = torch.cuda.Event()
+            self._copied[turn].record()
         if src_rows is not None:
             src = self.src_rows[:n]
             self.input_ids[:n] = torch.where(src >= 0, prev_tokens[src.clamp(min=0)], self.input_ids[:n])
@@ -169,6 +191,14 @@ class ModelRunner:
         # kernels of a step are launch-latency-bound on small models.  No counterpart in the
         # reference (its README lists CUDA graphs as future work).
         self.use_graphs = use_graphs and self.device.type == "cuda"
+        shard = getattr(model, "shard", None)
+        self.sharded = shard is not None and shard.world > 1
+        self.group = getattr(model, "group", None)
+        if self.use_graphs and self.sharded:
+            import torch.distributed as dist
+            if dist.get_backend(self.group) != "nccl":
+                raise ValueError("use_graphs with a head-sharded model needs the RCCL ('nccl') backend: the per-layer "
+                                 f"all-gather of backend {dist.get_backend(self.group)!r} cannot be captured in a HIP graph")
         self._graphs: dict[tuple[int, int], _DecodeGraph] = {}
 
     # ---- KV cache -------------------------------------------------------------------------
@@ -220,6 +250,13 @@ class ModelRunner:
         set_context(ctx)
         return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
 
+    def _sample(self, logits: torch.Tensor, temperatures: list[float]) -> torch.Tensor:
+        tokens = sample(logits, temperatures)
+        if self.sharded and any(t != 0 for t in temperatures):
+            from ..parallel import broadcast_tokens
+            tokens = broadcast_tokens(tokens, self.group)      # rank 0's draw; argmax is identical everywhere
+        return tokens
+
     def _graph_for(self, n_seqs: int, table_width: int) -> _DecodeGraph:
         # batch buckets: 1, 2, 4, 8, then multiples of 16 (the kernels plan their launch from the padded
         # batch, so padding a small batch to 16 would halve its useful waves)
@@ -266,7 +303,7 @@ class ModelRunner:
                 src_d = self._to_device(src)
                 input_ids = torch.where(src_d >= 0, prev_tokens[src_d.clamp(min=0)], input_ids)
             logits = self.model(input_ids, positions)
-        tokens = sample(logits, [s.sampling_params.temperature for s in seqs])
+        tokens = self._sample(logits, [s.sampling_params.temperature for s in seqs])
         handle = {"rows": {s.id: i for i, s in enumerate(seqs)}, "tokens": tokens, "event": None}
         if self.device.type == "cuda":
             host = torch.empty(len(seqs), dtype=torch.int64, pin_memory=True)
@@ -287,7 +324,7 @@ class ModelRunner:
     @torch.inference_mode()
     def run(self, seqs: list[Sequence]) -> list[int | None]:
         """Forward the scheduled tokens; returns one sampled token per sequence, or None while a
-        sequence's prompt is still being chunked (model_runner.py:214-240)."""
+        sequence's prompt is still being chunked or its K/V is being recomputed (model_runner.py:214-240)."""
         if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
             m = prepare_inputs(seqs, self.block_size)
             g = self._graph_for(len(seqs), m["block_tables"].shape[1])
@@ -298,12 +335,8 @@ class ModelRunner:
             last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)
             logits = self.model(input_ids, positions, logits_rows=last_rows)      # [B, vocab]
         temps = [s.sampling_params.temperature for s in seqs]
-        tokens = sample(logits, temps).tolist()
-        out = []
-        for seq, tok in zip(seqs, tokens):
-            complete = seq.num_computed_tokens + seq.num_scheduled_tokens >= len(seq.prompt_tokens)
-            out.append(tok if complete else None)
-        return out
+        tokens = self._sample(logits, temps).tolist()
+        return [tok if seq.completes_step else None for seq, tok in zip(seqs, tokens)]
 
 
 def sample(logits: torch.Tensor, temperatures: list[float]) -> torch.Tensor:

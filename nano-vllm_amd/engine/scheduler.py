@@ -4,9 +4,15 @@ Policy of the reference's nanovllm/engine/scheduler.py:30-160: running sequences
 token, or the next prompt chunk of at most `long_prefill_token_threshold` tokens), then waiting
 sequences while the token budget `max_num_batched_tokens` lasts; admission looks up the prefix
 cache and allocates blocks for the first chunk only; a sequence finishes on `max_tokens` or EOS and
-its blocks are released.  A running sequence that cannot get a block is left out of the step (the
-reference prints and drops it from the queue, scheduler.py:52-57); `max_num_seqs` is enforced only
-when set (the reference stores it and never reads it).
+its blocks are released.  `max_num_seqs` is enforced only when set (the reference stores it and never
+reads it).
+
+When a running sequence cannot get a block the reference prints and drops it from the queue
+(scheduler.py:52-57), which loses the request.  Here the youngest running sequence is preempted
+instead: its blocks are released, it returns to the head of the waiting queue and its K/V
+(prompt and the tokens generated so far) is recomputed on re-admission, through the prefix cache
+where its blocks survived.  Admission also asks for enough free blocks for the whole prompt (a
+check, not a reservation), so that a long prompt is not admitted only to be preempted again.
 """
 from __future__ import annotations
 
@@ -40,36 +46,62 @@ class Scheduler:
         bm = self.block_manager
         budget = self.max_scheduled_tokens
         scheduled: list[Sequence] = []
-        # 1. running sequences: decode token or next prompt chunk
-        for seq in self.running:
+        # 1. running sequences, oldest first: decode token, next prompt chunk, or next chunk of a
+        #    recomputation.  Tokens [computed, computed + n_new) of prompt + outputs are processed.
+        running = list(self.running)
+        preempted: list[Sequence] = []
+        i = 0
+        while i < len(running):
+            seq = running[i]
             seq.num_scheduled_tokens = 0
             if budget <= 0 or seq.is_finished:
+                i += 1
                 continue
-            remaining = len(seq.prompt_tokens) - seq.num_computed_tokens
-            n_new = min(remaining, self.long_prefill_token_threshold, budget) if remaining > 0 else 1
-            try:
-                bm.append_slots(seq, n_new)
-            except ValueError:
-                continue                       # no block available: sits this step out
-            seq.num_scheduled_tokens = n_new
-            bm.publish_full_blocks(seq, seq.num_computed_tokens + n_new)
-            budget -= n_new
-            scheduled.append(seq)
-        # 2. admit waiting sequences
+            n_new = min(len(seq) - seq.num_computed_tokens, self.long_prefill_token_threshold, budget)
+            got = False
+            while True:
+                try:
+                    bm.append_slots(seq, n_new)
+                    got = True
+                    break
+                except ValueError:
+                    victim = self._pick_victim(running, i)
+                    if victim is None:
+                        break                  # nobody can give way right now: sits this step out
+                    running.remove(victim)
+                    self._preempt(victim)
+                    preempted.append(victim)
+                    if victim is seq:
+                        break
+            if got:
+                seq.num_scheduled_tokens = n_new
+                bm.publish_full_blocks(seq, seq.num_computed_tokens + n_new)
+                budget -= n_new
+                scheduled.append(seq)
+                i += 1
+            elif i < len(running) and running[i] is seq:
+                i += 1                         # still running, not scheduled
+        if preempted:
+            self.running = deque(running)
+            for victim in preempted:           # youngest was preempted first: oldest ends up at the head
+                self.waiting.appendleft(victim)
+        # 2. admit waiting sequences (not in a step that had to preempt: the cache is full)
         admitted = 0
-        while self.waiting and budget > 0:
+        while self.waiting and budget > 0 and not preempted:
             if self.max_num_seqs is not None and len(self.running) >= self.max_num_seqs:
                 break
             seq = self.waiting[0]
-            cached_blocks, n_cached = bm.get_computed_blocks(seq.prompt_tokens)
-            n_new = len(seq.prompt_tokens) - n_cached
+            tokens = seq.token_ids if seq.output_tokens else seq.prompt_tokens   # all of it after a preemption
+            cached_blocks, n_cached = bm.get_computed_blocks(tokens)
+            n_new = len(tokens) - n_cached
             if 0 < self.long_prefill_token_threshold < n_new:
                 n_new = self.long_prefill_token_threshold
             n_new = min(n_new, budget)
             # blocks for tokens [n_cached, n_cached + n_new); n_cached is block aligned
             blocks_needed = -(-n_new // self.block_size)
+            blocks_whole = -(-(len(tokens) + 1) // self.block_size) - len(cached_blocks)   # prompt + first new token
             idle_hits = sum(1 for b in cached_blocks if bm.block_pool[b].ref_count == 0)
-            if not bm.can_allocate(blocks_needed + idle_hits):
+            if not bm.can_allocate(max(blocks_needed, blocks_whole) + idle_hits):
                 break
             bm.allocate_slots(seq, cached_blocks, blocks_needed)
             seq.num_computed_tokens = n_cached
@@ -83,6 +115,25 @@ class Scheduler:
             scheduled.append(seq)
             admitted += 1
         return scheduled, admitted > 0
+
+    @staticmethod
+    def _pick_victim(running: list[Sequence], current: int) -> Sequence | None:
+        """Youngest running sequence at or after position `current` whose token values are all known
+        on the host (a sequence with a token still in flight cannot be recomputed yet)."""
+        for j in range(len(running) - 1, current - 1, -1):
+            cand = running[j]
+            if not cand.is_finished and cand.num_pending == 0:
+                return cand
+        return None
+
+    def _preempt(self, seq: Sequence) -> None:
+        """Recompute-preemption: release the blocks, forget the computed count, back to waiting."""
+        self.block_manager.free_sequence(seq.id)
+        seq.block_table = []
+        seq.num_computed_tokens = 0
+        seq.num_scheduled_tokens = 0
+        seq.num_preemptions += 1
+        seq.status = SequenceStatus.WAITING
 
     def _retire(self, finished: list[Sequence]) -> None:
         for seq in finished:

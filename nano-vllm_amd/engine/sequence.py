@@ -38,6 +38,7 @@ class Sequence:
         self.block_table: list[int] = []  # physical block ids, logical order
         self.num_pending = 0              # trailing output tokens that are still PENDING (0 or 1)
         self.stopped_early = False        # finished on EOS while a later step was already in flight
+        self.num_preemptions = 0          # times its blocks were taken away and its K/V recomputed
         self.sampling_params = sampling_params or SamplingParams()
 
     def __len__(self) -> int:
@@ -53,6 +54,13 @@ class Sequence:
     def is_prefill(self) -> bool:
         """No sampled token yet (sequence.py:45-49)."""
         return not self.output_tokens
+
+    @property
+    def completes_step(self) -> bool:
+        """The scheduled tokens reach the end of the sequence, so the step's last logit row samples
+        its next token.  False while a prompt is being chunked or a preempted sequence is being
+        recomputed."""
+        return self.num_computed_tokens + self.num_scheduled_tokens >= len(self)
 
     @property
     def last_token(self) -> int:

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..parallel import all_gather_heads
+from ..parallel import HeadGather
 
 from ..utils.cache_context import get_context
 
@@ -98,9 +98,11 @@ class Qwen3Attention(nn.Module):
     heads: q/k/v_proj hold the matching rows, the KV cache has H_kv/N heads, and the head outputs
     of all ranks are all-gathered before the (replicated) o_proj."""
 
-    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
+    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None, gather=None):
         super().__init__()
         self.shard, self.group = shard, group
+        # one HeadGather (persistent all-gather buffers) is shared by all layers of a model
+        self._gather = gather if gather is not None else (HeadGather(shard, group) if shard is not None else None)
         self.head_dim = cfg.head_dim
         self.num_heads = shard.local_heads if shard else cfg.num_attention_heads
         self.num_kv_heads = shard.local_kv_heads if shard else cfg.num_key_value_heads
@@ -155,7 +157,7 @@ class Qwen3Attention(nn.Module):
             q, k = self.rope(positions, q, k)
             o = self.attention(q, k, v)
         if self.shard is not None and self.shard.world > 1:
-            o = all_gather_heads(o.reshape(-1, self.num_heads, self.head_dim), self.shard, self.group)
+            o = self._gather(o.reshape(-1, self.num_heads, self.head_dim))
         return self.o_proj(o.reshape(o.shape[0], -1))
 
 
@@ -183,9 +185,9 @@ class Qwen3MLP(nn.Module):
 
 
 class Qwen3DecoderLayer(nn.Module):
-    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
+    def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None, gather=None):
         super().__init__()
-        self.self_attn = Qwen3Attention(cfg, L, fused, shard, group)
+        self.self_attn = Qwen3Attention(cfg, L, fused, shard, group, gather)
         self.mlp = Qwen3MLP(cfg, L)
         self.input_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
@@ -205,7 +207,8 @@ class Qwen3Model(nn.Module):
     def __init__(self, cfg: ModelConfig, L, fused: bool, shard=None, group=None):
         super().__init__()
         self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
-        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, L, fused, shard, group)
+        gather = HeadGather(shard, group) if shard is not None else None
+        self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, L, fused, shard, group, gather)
                                     for _ in range(cfg.num_hidden_layers))
         self.norm = L.RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 
@@ -225,7 +228,7 @@ class Qwen3ForCausalLM(nn.Module):
         ranks of `group`, everything else replicated)."""
         super().__init__()
         L = layers if layers is not None else _default_layers()
-        self.config, self.shard = cfg, shard
+        self.config, self.shard, self.group = cfg, shard, group
         if shard is not None and (shard.num_heads, shard.num_kv_heads) != (cfg.num_attention_heads,
                                                                              cfg.num_key_value_heads):
             raise ValueError("HeadShard head counts do not match the model config")

@@ -71,3 +71,44 @@ def all_gather_heads(o_local: torch.Tensor, shard: HeadShard, group=None, out: t
         out = torch.empty((T, shard.world * hl, d), dtype=o_local.dtype, device=o_local.device)
     out.view(T, shard.world, hl, d).copy_(staging.view(shard.world, T, hl, d).permute(1, 0, 2, 3))
     return out
+
+
+class HeadGather:
+    """all_gather_heads with buffers that persist across calls: the model path allocates nothing per
+    layer (one instance serves every layer of a model: layers run one after another on one stream),
+    which also makes the step capturable in a HIP graph once the buffers have reached their size.
+    The buffers grow (a new allocation) only when a step has more tokens than any step before.
+
+    Why the strided copy stays: the all-gather delivers rank-major [N, T, H_q/N, D], o_proj wants
+    token-major rows [T, H_q*D].  Consuming the rank-major buffer directly would turn o_proj into N
+    accumulating GEMMs of depth H_q*D/N each; at decode sizes one 4 MiB device copy is cheaper than
+    N - 1 extra GEMM launches."""
+
+    def __init__(self, shard: HeadShard, group=None):
+        self.shard, self.group = shard, group
+        self._staging: torch.Tensor | None = None
+        self._out: torch.Tensor | None = None
+
+    def _reserve(self, T: int, hl: int, d: int, like: torch.Tensor) -> None:
+        n = self.shard.world
+        if (self._staging is None or self._staging.shape[0] < n * T or self._staging.device != like.device
+                or self._staging.dtype != like.dtype or self._staging.shape[1:] != (hl, d)):
+            self._staging = torch.empty((n * T, hl, d), dtype=like.dtype, device=like.device)
+            self._out = torch.empty((T, n * hl, d), dtype=like.dtype, device=like.device)
+
+    def __call__(self, o_local: torch.Tensor) -> torch.Tensor:
+        if self.shard.world == 1:
+            return o_local
+        T, hl, d = o_local.shape
+        self._reserve(T, hl, d, o_local)
+        return all_gather_heads(o_local, self.shard, self.group, out=self._out[:T],
+                                staging=self._staging[:self.shard.world * T])
+
+
+def broadcast_tokens(tokens: torch.Tensor, group=None, src: int = 0) -> torch.Tensor:
+    """Make every rank of a head-sharded engine continue with rank `src`'s sampled tokens.  Logits are
+    replicated, but a random draw (temperature > 0) comes from each rank's own generator; ranks that
+    disagreed on a token would schedule different batches and the next all-gather would mismatch."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(tokens, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    return tokens

@@ -304,3 +304,55 @@ def test_safetensors_loader_round_trip(tmp_path):
         load_model(Qwen3ForCausalLM(cfg, layers=ref_modules, fused=False), str(tmp_path))
     with pytest.raises(FileNotFoundError):
         load_model(dst, str(tmp_path / "nowhere"))
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_preemption_when_the_cache_is_too_small_for_all_requests(pipelined):
+    """Requests that together outgrow the KV cache: the youngest running sequence is preempted (blocks
+    released, K/V recomputed later) instead of the loop spinning or a request being dropped; every
+    request finishes with exactly the tokens it gets from an engine with a large cache."""
+    g = torch.Generator().manual_seed(11)
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (180, 170, 60)]
+    params = [SamplingParams(0.0, n) for n in (40, 30, 50)]
+    big, _ = _tiny_engine(16, 64)
+    want, _ = big.generate(prompts, params)
+    # 16 blocks of 16 tokens = 256 tokens of cache for 220 + 200 + 110 tokens of requests
+    small, _ = _tiny_engine(16, 16, pipelined_decode=pipelined)
+    seqs_before = small.scheduler.block_manager.num_free_blocks
+    got, m = small.generate(prompts, params)
+    assert [o["token_ids"] for o in got] == [o["token_ids"] for o in want]
+    assert small.scheduler.block_manager.num_free_blocks == seqs_before == 16
+    assert m.num_generated_tokens == 120
+
+
+def test_preemption_counts_and_order():
+    """Scheduler level: with one free block left the older sequence grows and the younger is preempted to
+    the head of the waiting queue; it is re-admitted only when its whole prompt fits again."""
+    sched = Scheduler(4, 4, max_num_batched_tokens=64, long_prefill_token_threshold=64, eos=-1)
+    a, b = Sequence(list(range(7)), SamplingParams(0.0, 8)), Sequence(list(range(20, 27)), SamplingParams(0.0, 8))
+    sched.add(a)
+    sched.add(b)
+    tok = 100
+    for _ in range(2):                                   # prefill, then one decode step: both second blocks are full
+        seqs, _ = sched.schedule()
+        sched.update_from_output(seqs, [tok + i for i in range(len(seqs))])
+    assert sched.block_manager.num_free_blocks == 0 and len(a) == len(b) == 9   # 2 blocks each; token 9 needs a third
+    seqs, admitted = sched.schedule()
+    assert seqs == [a] and not admitted and b.num_preemptions == 1 and list(sched.waiting) == [b]
+    assert b.num_computed_tokens == 0 and b.block_table == [] and len(a.block_table) == 3
+    sched.update_from_output(seqs, [7])
+    seqs, admitted = sched.schedule()                    # b needs 3 blocks (10 tokens + 1), only 1 is free
+    assert seqs == [a] and not admitted
+    while not a.is_finished:
+        sched.update_from_output(seqs, [7])
+        seqs, admitted = sched.schedule()
+    assert b in seqs and admitted and b.num_scheduled_tokens == len(b) - b.num_computed_tokens
+
+
+def test_requests_that_can_never_fit_are_refused():
+    eng, cfg = _tiny_engine(16, 4)
+    with pytest.raises(ValueError, match="KV-cache blocks"):
+        eng.add_request(list(range(60)), SamplingParams(0.0, 10))          # 70 tokens > 4 blocks x 16
+    with pytest.raises(ValueError, match="max_position_embeddings"):
+        _tiny_engine(16, 128)[0].add_request(list(range(1000)), SamplingParams(0.0, 100))
+    eng.add_request(list(range(50)), SamplingParams(0.0, 14))              # exactly 64 tokens: accepted

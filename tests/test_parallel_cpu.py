@@ -86,6 +86,19 @@ def _engine_worker(rank, world, port, result_path):
         outs, _ = eng.generate(prompts, SamplingParams(0.0, 5))
         ref_outs, _ = LLMEngine(full, cfg, **kw).generate(prompts, SamplingParams(0.0, 5))
         ok = ok and [o["token_ids"] for o in outs] == [o["token_ids"] for o in ref_outs]
+        # the all-gather buffers persist: one pair for all layers, no allocation per layer or per step
+        gathers = {id(layer.self_attn._gather) for layer in part.model.layers}
+        buf = part.model.layers[0].self_attn._gather._staging
+        ok = ok and len(gathers) == 1 and buf is not None
+        # temperature > 0 with DIFFERENT generator states per rank: rank 0's draws are broadcast, so the
+        # ranks keep scheduling identical batches (a mismatch would hang or corrupt the next all-gather)
+        torch.manual_seed(1000 + rank)
+        sampled, _ = LLMEngine(part, cfg, **kw).generate(prompts, SamplingParams(0.8, 6))
+        ok = ok and part.model.layers[0].self_attn._gather._staging is buf
+        mine = torch.tensor([o["token_ids"] for o in sampled])
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        ok = ok and all(torch.equal(b, both[0]) for b in both)
         flags = [torch.zeros(1) for _ in range(world)]
         dist.all_gather(flags, torch.tensor([1.0 if ok else 0.0]))
         if rank == 0:
