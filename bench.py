@@ -10,12 +10,16 @@ over all 28 layers: per layer two residual-add RMSNorms at hidden size, the fuse
 rotary + KV-cache scatter, and paged decode attention.  Inputs are resident in HBM before the
 timed region.
 
-`value` = algorithmic HBM bytes of the whole step / wall time of the step (GB/s).
-`roofline` is for the dominant kernel (paged decode attention): algorithmic bytes per launch
+`value` = algorithmic HBM bytes of the whole step / wall time of the step (GB/s);
+`step_pct_of_hbm_peak` is that figure per GPU against 8 TB/s.
+`roofline` is for the dominant kernel (paged decode attention) alone: algorithmic bytes per launch
 (4096 B per cached token + 8 KiB of Q/O + table bytes, summed over the batch) divided by the
-average launch duration measured with HIP events on the launch stream inside the timed steps.
-`cpu_baseline` times the CPU oracle (torch, fp32) of the same attention on a bounded sample
-on the host cores (rank 0, N=1 only).
+average launch duration measured with HIP events on the launch stream inside the timed steps
+(`attn_kernel_pct_of_hbm_peak` repeats its fraction).
+`prefill` (rank 0): the bf16 MFMA prefill kernel on BASELINE config 3 shapes against the 2.5 PFLOP/s peak.
+`decode_by_config` (rank 0): the decode launch at the per-GPU shapes of configs 4 and 5.
+`cpu_baseline` times the CPU oracle (torch, fp32) of the same attention, and of the scatter / norm /
+rotary / prefill kernels, on bounded samples on the host cores (rank 0, N=1 only).
 
 N>1 (launched by torch.distributed.run, one rank per GPU): every rank runs an independent
 replica of the same batch (data-parallel replicas, no data-path collective; weak scaling);
@@ -53,6 +57,8 @@ def parse():
     ap.add_argument("--tp-layers", type=int, default=8, help="layers in the head-sharded sub-benchmark")
     ap.add_argument("--no-tp", action="store_true", help="skip the head-sharded sub-benchmark")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end generation run (N=1 only)")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prefill-attention records (rank 0)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the decode records at config 4 / 5 shapes (rank 0)")
     return ap.parse_args()
 
 
@@ -199,6 +205,179 @@ def reduce_scalar(dist, dev, value: float, op: str) -> float:
     return t.item()
 
 
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak
+
+
+def _paged_layout(n_ks, bs, seed, dev):
+    """Shuffled physical blocks and -1 padded tables for sequences of n_ks keys."""
+    blocks = [math.ceil(n / bs) for n in n_ks]
+    NB = sum(blocks)
+    g = torch.Generator().manual_seed(seed)
+    perm = torch.randperm(NB, generator=g).tolist()
+    width = max(blocks)
+    tables, nxt = [], 0
+    for nb in blocks:
+        tables.append(perm[nxt:nxt + nb] + [-1] * (width - nb))
+        nxt += nb
+    bt = torch.tensor(tables, dtype=torch.int32, device=dev)
+    cu_k = torch.tensor([0] + torch.tensor(n_ks).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+    return NB, width, bt, cu_k
+
+
+def _time_launches(fn, n_variants, iters, dev):
+    """Average milliseconds of fn(i % n_variants) over `iters` back-to-back launches (HIP events on the
+    launch stream, two untimed warm-up launches per variant)."""
+    for i in range(2 * n_variants):
+        fn(i % n_variants)
+    torch.cuda.synchronize(dev)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(iters):
+        fn(i % n_variants)
+    b.record()
+    torch.cuda.synchronize(dev)
+    return a.elapsed_time(b) / iters
+
+
+def prefill_records(dev, iters=10):
+    """Prefill / chunked-prefill attention (bf16 MFMA kernel) on BASELINE config 3 shapes (Qwen3-8B attention:
+    32 query / 8 kv heads x 128, block 256).  flops = 4 * D * H_q * visible (query, key) pairs."""
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bs, D, H_q, H_kv = 256, 128, 32, 8
+    cases = [
+        ("one 8192-token prompt prefilled as 16 chunks of 512 (16 launches, keys 512..8192)",
+         [([512], [512 * (c + 1)]) for c in range(16)]),
+        ("last chunk of that prompt alone: 512 queries over 8192 cached keys", [([512], [8192])]),
+        ("7 sequences in one step, a 512-token chunk each, cached keys 512..8192",
+         [([512] * 7, [512, 1024, 2048, 4096, 8192, 6144, 3072])]),
+        ("4 sequences x 8192 tokens, whole-prompt prefill", [([8192] * 4, [8192] * 4)]),
+    ]
+    out = []
+    for label, launches in cases:
+        n_ks_all = launches[-1][1] if len(launches) > 1 else launches[0][1]
+        NB, width, bt, _ = _paged_layout(n_ks_all, bs, 3, dev)
+        kc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
+        vc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
+        plans, flops = [], 0
+        for n_qs, n_ks in launches:
+            B, T = len(n_qs), sum(n_qs)
+            q = torch.randn(T, H_q, D, device=dev).bfloat16()
+            o = torch.empty_like(q)
+            cu_q = torch.tensor([0] + torch.tensor(n_qs).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+            cu_k = torch.tensor([0] + torch.tensor(n_ks).cumsum(0).tolist(), dtype=torch.int32, device=dev)
+            ws = torch.empty(max(16, dll.nv_attn_prefill_workspace_bytes(B, T, max(n_qs), max(n_ks), H_q, H_kv, D)),
+                             dtype=torch.uint8, device=dev)
+            plans.append((q, o, cu_q, cu_k, ws, (q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), cu_q.data_ptr(),
+                                                cu_k.data_ptr(), bt.data_ptr(), B, width, max(n_qs), max(n_ks), H_q, H_kv, D,
+                                                NB, bs, D ** -0.5, q.stride(0), o.stride(0), 0, T, ws.data_ptr(), ws.numel(),
+                                                stream)))
+            flops += sum(4 * D * H_q * (nq * (nk - nq) + nq * (nq + 1) // 2) for nq, nk in zip(n_qs, n_ks))
+
+        def run_all(_):
+            for pl in plans:
+                rc = dll.nv_attn_prefill_varlen(*pl[-1])
+                if rc != 0:
+                    _lib.check(rc, "nv_attn_prefill_varlen")
+        ms = _time_launches(run_all, 1, iters, dev)
+        tf = flops / (ms * 1e-3) / 1e12
+        out.append({"workload": f"Qwen3-8B attention shapes (H {H_q}/{H_kv}, D {D}, block {bs}): {label}",
+                    "launches": len(plans), "flops": flops, "ms": round(ms, 4), "achieved_tflops": round(tf, 1),
+                    "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4)})
+        del plans, kc, vc
+        torch.cuda.empty_cache()
+    return out
+
+
+def decode_config_records(dev, iters=40):
+    """Decode attention launch at the per-GPU shapes of BASELINE config 4 (Qwen3-32B, 64 query / 8 kv heads,
+    batch 256, ctx 2048, kv heads 8/4/2/1 per GPU = 1/2/4/8-way head sharding) and config 5 (Llama-3.1-8B,
+    32/8 heads, ctx 32768, 1/4/8 sequences per replica).  Several layers' caches are cycled so that every
+    launch streams from HBM (working set > 512 MB)."""
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    bs, D = 256, 128
+    shapes = [("config 4", 256, 2048, 8 * hkv, hkv) for hkv in (8, 4, 2, 1)] + \
+             [("config 5", b, 32768, 32, 8) for b in (8, 4, 1)]
+    out = []
+    for cfg_name, B, ctx, H_q, H_kv in shapes:
+        n_ks = [ctx] * B
+        NB, width, bt, cu_k = _paged_layout(n_ks, bs, 5, dev)
+        layer_bytes = 2 * NB * bs * H_kv * D * 2
+        L = max(1, min(8, -(-(768 << 20) // layer_bytes)))
+        caches = [(torch.randn(NB, bs, H_kv, D, device=dev).bfloat16(), torch.randn(NB, bs, H_kv, D, device=dev).bfloat16())
+                  for _ in range(L)]
+        q = torch.randn(B, H_q, D, device=dev).bfloat16()
+        o = torch.empty_like(q)
+        cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(16, dll.nv_attn_decode_workspace_bytes(B, H_q, H_kv, D, ctx)), dtype=torch.uint8, device=dev)
+
+        def launch(l):
+            rc = dll.nv_attn_decode_paged(q.data_ptr(), caches[l][0].data_ptr(), caches[l][1].data_ptr(), o.data_ptr(),
+                                          cu_q.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B, width, ctx, H_q, H_kv, D, NB,
+                                          bs, D ** -0.5, q.stride(0), o.stride(0), ws.data_ptr(), ws.numel(), stream)
+            if rc != 0:
+                _lib.check(rc, "nv_attn_decode_paged")
+        ms = _time_launches(launch, L, iters, dev)
+        nbytes = B * (2 * ctx * H_kv * D * 2 + 2 * H_q * D * 2 + 4 * math.ceil(ctx / bs) + 8)
+        gbps = nbytes / (ms * 1e-3) / 1e9
+        out.append({"workload": f"{cfg_name}: batch {B}, ctx {ctx}, H {H_q}/{H_kv} per GPU, block {bs}",
+                    "bytes": nbytes, "ms": round(ms, 5), "achieved_GBps": round(gbps, 1), "peak": HBM_PEAK_GBPS,
+                    "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+        del caches
+        torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline_other(seconds_each: float = 3.0):
+    """The oracle's remaining kernels on the host cores, bounded samples: KV scatter, residual-add RMSNorm,
+    rotary embedding (GB/s of the same algorithmic bytes as the GPU kernels) and prefill attention (TFLOP/s)."""
+    from oracle import ref_attention, ref_layers
+    threads = torch.get_num_threads()
+    out = {}
+
+    def rate(fn, per_call):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds_each:
+            fn()
+            n += 1
+        return n * per_call / (time.perf_counter() - t0)
+
+    T, H_q, H_kv, D, hidden, bs = 4000, 16, 8, 128, 1024, 256
+    g = torch.Generator().manual_seed(0)
+    k = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    v = torch.randn(T, H_kv, D, generator=g).bfloat16()
+    kc = torch.zeros(32, bs, H_kv, D, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    slots = torch.randperm(32 * bs, generator=g)[:T].to(torch.int32)
+    out["store_kvcache_GBps"] = round(rate(lambda: ref_attention.store_kvcache_ref(k, v, kc, vc, slots, bs),
+                                           T * (2 * H_kv * D * 2) * 2 + 4 * T) / 1e9, 3)
+    x = torch.randn(T, hidden, generator=g).bfloat16()
+    res = torch.randn(T, hidden, generator=g).bfloat16()
+    w = torch.ones(hidden).bfloat16()
+    out["add_rmsnorm_GBps"] = round(rate(lambda: ref_layers.rmsnorm_ref(x, w, 1e-6, res), T * hidden * 2 * 4 + hidden * 2) / 1e9, 3)
+    table = ref_layers.build_cos_sin_cache(D, 4096, 1e6)
+    pos = torch.randint(0, 4096, (T,), generator=g)
+    q = torch.randn(T, H_q, D, generator=g).bfloat16()
+    out["rope_GBps"] = round(rate(lambda: ref_layers.rope_ref(pos, q, k, table),
+                                  T * (H_q + H_kv) * D * 2 * 2 + T * D * 4 + 8 * T) / 1e9, 3)
+    n = 512                                                   # config 2 prefill: one 512-token sequence, H 16/8
+    qp = torch.randn(n, H_q, D, generator=g).bfloat16()
+    kc2 = torch.randn(2, bs, H_kv, D, generator=g).bfloat16()
+    vc2 = torch.randn(2, bs, H_kv, D, generator=g).bfloat16()
+    cu = torch.tensor([0, n], dtype=torch.int32)
+    bt = torch.tensor([[0, 1]], dtype=torch.int32)
+    flops = 4 * D * H_q * (n * (n + 1) // 2)
+    out["prefill_attention_TFLOPs"] = round(rate(lambda: ref_attention.paged_attention_ref(qp, kc2, vc2, cu, cu, bt, D ** -0.5),
+                                                 flops) / 1e12, 4)
+    out["sample"] = (f"oracle (torch fp32, {threads} threads), ~{seconds_each:.0f} s each: scatter / add+RMSNorm / rotary of "
+                     f"{T} tokens (Qwen3-0.6B shapes), prefill attention of one 512-token sequence")
+    return out
+
+
 def tp_bench(args, dev, rank, world, dist):
     """Head-sharded decode attention + all-gather of head outputs (BASELINE config 4 shapes:
     Qwen3-32B attention, H_q=64, H_kv=8, D=128, batch 256, ctx 2048, block 256).  Rank r holds kv heads
@@ -260,7 +439,11 @@ def tp_bench(args, dev, rank, world, dist):
     t_attn = timed(False)
     t_full = timed(world > 1)
     bytes_layer_all = B * (2 * CTX * H_KV * D * 2 + 2 * H_Q * D * 2 + 4 * nb_seq + 8)     # all ranks together
-    return {"workload": f"Qwen3-32B attention shapes, decode batch {B}, ctx {CTX}, block {BS}, {L} layers, "
+    if dist is not None:
+        assert dist.get_world_size() == world == args.gpus, "process group size differs from --gpus"
+    return {"world_size": world,
+            "ms_allgather_per_layer": round(max(t_full - t_attn, 0.0) / L * 1e3, 4),
+            "workload": f"Qwen3-32B attention shapes, decode batch {B}, ctx {CTX}, block {BS}, {L} layers, "
                         f"kv heads sharded {H_KV}/{world} per GPU, RCCL all-gather of o per layer",
             "ms_per_layer_attn_only": round(t_attn / L * 1e3, 4),
             "ms_per_layer_with_allgather": round(t_full / L * 1e3, 4),
@@ -328,36 +511,66 @@ def main():
     torch.cuda.empty_cache()
     tp = None if args.no_tp else tp_bench(args, dev, rank, world, dist)
 
+    extra_prefill = extra_cfg = None
+    if rank == 0 and not args.no_prefill:
+        extra_prefill = prefill_records(dev)
+    if rank == 0 and not args.no_configs:
+        extra_cfg = decode_config_records(dev)
+
     if rank == 0:
-        traffic = None
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be
+        # read inside this process); it is reported only while the kernel source and the workload are the
+        # ones the passes were taken on.
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "decode_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                rec = json.load(open(tf))
+                import hashlib
+                src = os.path.join(ROOT, "nano-vllm_amd", "csrc", "attn_decode.hip")
+                sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+                default_wl = (args.batch, args.ctx_lo, args.ctx_hi) == (256, 513, 768)
+                if rec.get("kernel_source_sha256") == sha and default_wl:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = {"file": "profiles/decode_traffic.json", "commit": rec.get("commit"),
+                                      "kernel_source_sha256": sha[:16], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                      "separate passes, FETCH_SIZE doubled (gfx950)"}
+                else:
+                    traffic_source = {"file": "profiles/decode_traffic.json", "stale": True,
+                                      "reason": "kernel source or workload differs from the PMC passes"}
             except Exception:
                 traffic = None
         out = {
             "metric": "paged-decode attn HBM GB/s", "value": round(value, 1), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "value_scope": "whole decode step of the hot path (all kernels of all layers): algorithmic bytes / wall time",
             "config": {"workload": f"Qwen3-0.6B shapes, decode batch {args.batch}, ctx U[{args.ctx_lo},{args.ctx_hi}], "
                                    f"block 256, {args.layers} layers; step = "
                                    + ("decode attention only" if args.attn_only else
                                       "2x add+RMSNorm, fused qk-norm+RoPE+KV store, paged decode attention per layer"),
                        "H_q": 16, "H_kv": 8, "head_dim": 128, "batch": args.batch, "layers": args.layers,
                        "parallelism": "single GPU" if world == 1 else f"dp{world} replicas"
-                                      + (" (REHEARSAL: ranks share one GPU, gloo)" if share else "")},
-            "pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
+                                      + (" (REHEARSAL: ranks share one GPU, gloo)" if share else ""),
+                       "world_size_checked": world if dist is None else dist.get_world_size()},
+            "step_pct_of_hbm_peak": round(100 * value / world / HBM_PEAK_GBPS, 2),
+            "attn_kernel_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "hot_path_tok_per_s": round(args.batch * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (+merge)", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decode attention launch only, rank 0)",
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": traffic, "launch_ms": round(attn_ms, 5),
+                         "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(attn_ms, 5),
                          "algorithmic_bytes_per_launch": w.attn_bytes_per_launch()},
         }
+        if extra_prefill is not None:
+            out["prefill"] = extra_prefill
+        if extra_cfg is not None:
+            out["decode_by_config"] = extra_cfg
         if tp is not None:
             out["head_sharded"] = tp
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(w, cpu_kv[0], cpu_kv[1], args.cpu_seconds)
+            out["cpu_baseline"]["other_kernels"] = cpu_baseline_other()
         if world == 1 and not args.no_e2e:
             # BASELINE config 2 end to end: 256 prompts x 512 tokens in, 256 out, argmax, random-init
             # Qwen3-0.6B-shaped weights; GEMMs are torch/hipBLASLt, the attention path is this library.

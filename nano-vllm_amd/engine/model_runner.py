@@ -44,7 +44,8 @@ def _prepare_decode_inputs(seqs: list[Sequence], block_size: int) -> dict:
     np.cumsum(start + 1, out=cu_k[1:])
     return dict(input_ids=input_ids, positions=positions, slot_mapping=slots.astype(np.int32), cu_seqlens_q=cu_q,
                 cu_seqlens_k=cu_k, max_seqlen_q=1, max_seqlen_k=int(start.max()) + 1, block_tables=tables,
-                num_decode_seqs=B)
+                num_decode_seqs=B, num_leading_decode=B, max_seqlen_k_decode=int(start.max()) + 1,
+                max_seqlen_q_rest=0, max_seqlen_k_rest=0)
 
 
 def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool = True) -> dict:
@@ -83,10 +84,15 @@ def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool
     cu_k = np.zeros(len(seqs) + 1, dtype=np.int32)
     np.cumsum(n_q, out=cu_q[1:])
     np.cumsum(n_k, out=cu_k[1:])
+    single = n_q == 1
+    lead = len(seqs) if single.all() else int(np.argmin(single))     # leading rows with one query token
     return dict(input_ids=np.concatenate(ids), positions=np.concatenate(pos),
                 slot_mapping=np.concatenate(slots).astype(np.int32), cu_seqlens_q=cu_q, cu_seqlens_k=cu_k,
                 max_seqlen_q=int(n_q.max()), max_seqlen_k=int(n_k.max()), block_tables=tables,
-                num_decode_seqs=n_decode)
+                num_decode_seqs=n_decode, num_leading_decode=lead,
+                max_seqlen_k_decode=int(n_k[:lead].max()) if lead else 0,
+                max_seqlen_q_rest=int(n_q[lead:].max()) if lead < len(seqs) else 0,
+                max_seqlen_k_rest=int(n_k[lead:].max()) if lead < len(seqs) else 0)
 
 
 class _DecodeGraph:
@@ -132,7 +138,8 @@ class _DecodeGraph:
         self.ctx = CacheContext(layer_idx=-1, is_prefill=False, slot_mapping=self.slot_mapping,
                                 cu_seqlens_q=self.cu_seqlens_q, cu_seqlens_k=self.cu_seqlens_k, max_seqlen_q=1,
                                 max_seqlen_k=width * runner.block_size, block_tables=self.block_tables,
-                                block_size=runner.block_size, num_decode_seqs=batch)
+                                block_size=runner.block_size, num_decode_seqs=batch, num_leading_decode=batch,
+                                max_seqlen_k_decode=width * runner.block_size)
         set_context(self.ctx)
         # warm-up on a side stream (library initialisation must not happen inside the capture)
         side = torch.cuda.Stream(device=dev)
@@ -246,7 +253,9 @@ class ModelRunner:
                            cu_seqlens_q=self._to_device(m["cu_seqlens_q"]),
                            cu_seqlens_k=self._to_device(m["cu_seqlens_k"]), max_seqlen_q=m["max_seqlen_q"],
                            max_seqlen_k=m["max_seqlen_k"], block_tables=self._to_device(m["block_tables"]),
-                           block_size=self.block_size, num_decode_seqs=m["num_decode_seqs"])
+                           block_size=self.block_size, num_decode_seqs=m["num_decode_seqs"],
+                           num_leading_decode=m["num_leading_decode"], max_seqlen_k_decode=m["max_seqlen_k_decode"],
+                           max_seqlen_q_rest=m["max_seqlen_q_rest"], max_seqlen_k_rest=m["max_seqlen_k_rest"])
         set_context(ctx)
         return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
 

@@ -56,6 +56,20 @@ class Attention(nn.Module):
             return ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k,
                                          ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
                                          cu_seqlens_q=ctx.cu_seqlens_q)
+        nd = ctx.num_leading_decode
+        if nd is not None:
+            # decode rows lead the batch: each kernel gets exactly its own sequences (no idle
+            # workgroups, and a launch plan sized from its own longest context)
+            o = torch.empty_like(q) if q.is_contiguous() else torch.empty(q.shape, dtype=q.dtype, device=q.device)
+            if nd > 0:
+                ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k[:nd + 1],
+                                      ctx.block_tables[:nd], ctx.max_seqlen_k_decode, self.attn_scale,
+                                      cu_seqlens_q=ctx.cu_seqlens_q[:nd + 1], out=o)
+            if nd < B:
+                ops.attn_prefill_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q[nd:], ctx.cu_seqlens_k[nd:],
+                                        ctx.block_tables[nd:], ctx.max_seqlen_q_rest, ctx.max_seqlen_k_rest,
+                                        self.attn_scale, skip_single_query=False, out=o)
+            return o
         n_dec = ctx.num_decode_seqs
         mixed = n_dec is None or n_dec > 0
         if n_dec is not None and n_dec == B:  # max_seqlen_q was an over-estimate

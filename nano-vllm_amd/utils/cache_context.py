@@ -3,8 +3,8 @@
 Same contract as the reference's ``nanovllm/utils/cache_context.py:6-39``: a dataclass held in
 a ``ContextVar``; ``Attention.forward`` fetches it with ``get_context()``, which raises
 ``RuntimeError`` when no context was set.  Field names and defaults match the reference; two
-optional fields are added for this implementation (``num_decode_seqs``, ``positions``) and are
-ignored by callers that do not know them.
+optional hints are added for this implementation (``num_decode_seqs``, ``num_leading_decode`` and
+its bounds) and may be left unset by callers that do not know them.
 """
 from __future__ import annotations
 
@@ -37,6 +37,15 @@ class CacheContext:
     # query token.  None = unknown; the attention layer then launches both of its kernels
     # whenever max_seqlen_q > 1 and lets each skip the rows that are not its regime.
     num_decode_seqs: Optional[int] = None
+    # Extension (optional): the first `num_leading_decode` sequences of the batch have exactly one
+    # query token each (schedulers put running sequences first), with `max_seqlen_k_decode` the
+    # longest of their contexts; `max_seqlen_q_rest` / `max_seqlen_k_rest` bound the sequences after
+    # them.  When given, a mixed step launches the decode kernel over the leading rows only and the
+    # prefill kernel over the rest, each planned from its own rows.
+    num_leading_decode: Optional[int] = None
+    max_seqlen_k_decode: int = 0
+    max_seqlen_q_rest: int = 0
+    max_seqlen_k_rest: int = 0
 
 
 _cache_context: ContextVar[Optional[CacheContext]] = ContextVar("CacheContext", default=None)

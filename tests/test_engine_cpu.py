@@ -356,3 +356,20 @@ def test_requests_that_can_never_fit_are_refused():
     with pytest.raises(ValueError, match="max_position_embeddings"):
         _tiny_engine(16, 128)[0].add_request(list(range(1000)), SamplingParams(0.0, 100))
     eng.add_request(list(range(50)), SamplingParams(0.0, 14))              # exactly 64 tokens: accepted
+
+
+def test_prepare_inputs_reports_leading_decode_rows():
+    """Hints for the attention layer: running (decode) sequences come first in a batch; the builder reports
+    how many leading sequences have one query token and the bounds of the two groups."""
+    def seq(prompt_len, outputs, computed, scheduled, table):
+        s = Sequence(list(range(prompt_len)), SamplingParams(0.0, 8))
+        s.output_tokens, s.num_computed_tokens, s.num_scheduled_tokens, s.block_table = outputs, computed, scheduled, table
+        return s
+    seqs = [seq(5, [7, 8], 6, 1, [0, 1]), seq(9, [3], 9, 1, [2, 3, 4]), seq(12, [], 4, 6, [5, 6, 7]), seq(3, [], 2, 1, [8])]
+    m = prepare_inputs(seqs, 4)
+    assert m["num_leading_decode"] == 2 and m["num_decode_seqs"] == 3
+    assert m["max_seqlen_k_decode"] == 10 and m["max_seqlen_q_rest"] == 6 and m["max_seqlen_k_rest"] == 10
+    m = prepare_inputs(seqs[:2], 4)
+    assert m["num_leading_decode"] == 2 and m["max_seqlen_q_rest"] == 0
+    m = prepare_inputs(seqs[2:], 4)
+    assert m["num_leading_decode"] == 0 and m["max_seqlen_k_decode"] == 0 and m["max_seqlen_q_rest"] == 6

@@ -486,12 +486,16 @@ def test_attention_module_forward_stores_then_attends(hip):
                                               p["block_tables"], p["scale"], bs)
     attn = nv.Attention(H_q, D, H_kv, p["scale"], 4096)
     attn.k_cache, attn.v_cache = p["k_cache"].to(DEV), p["v_cache"].to(DEV)
-    for n_dec in (None, 2):
+    # hints a caller may give: none; the number of one-token sequences; or "the first `lead` sequences are
+    # decode rows" with per-kernel bounds, which launches each kernel over its own rows only
+    lead_hint = dict(num_leading_decode=1, max_seqlen_k_decode=300, max_seqlen_q_rest=130, max_seqlen_k_rest=130)
+    for hints in (dict(), dict(num_decode_seqs=2), lead_hint, dict(num_leading_decode=0, max_seqlen_q_rest=130,
+                                                                  max_seqlen_k_rest=300)):
         nv.set_context(nv.CacheContext(slot_mapping=slots.to(DEV), cu_seqlens_q=p["cu_q"].to(DEV),
                                        cu_seqlens_k=p["cu_k"].to(DEV), max_seqlen_q=max(n_qs), max_seqlen_k=max(n_ks),
-                                       block_tables=p["block_tables"].to(DEV), block_size=bs, num_decode_seqs=n_dec))
+                                       block_tables=p["block_tables"].to(DEV), block_size=bs, **hints))
         o = attn(p["q"].to(DEV), k_new.to(DEV), v_new.to(DEV))
-        _attn_check(o, ref, "module")
+        _attn_check(o, ref, f"module {hints}")
     assert torch.equal(bits(attn.k_cache.cpu()), bits(kc_ref)) and torch.equal(bits(attn.v_cache.cpu()), bits(vc_ref))
     nv.set_context(None)
 
