@@ -57,6 +57,7 @@ typedef struct nv_tuning {
     int decode_mfma_depth;    /* -1 = heuristic; 0 / 1 = tiles prefetched ahead in the MFMA-score kernel  */
     int decode_single_launch; /* -1 = heuristic; 0 = separate merge launch; 1 = last-arriver merge        */
     int prefill_split;        /* 0 = heuristic; > 0: forced number of key-range splits                    */
+    int prefill_kernel;       /* -1 = heuristic; 0 = compiler-scheduled kernel; 1 = hand-scheduled kernel  */
 } nv_tuning;
 NV_API int nv_set_tuning(const nv_tuning* t);   /* NULL restores the heuristics */
 NV_API int nv_get_tuning(nv_tuning* out);

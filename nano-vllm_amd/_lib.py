@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnanovllm_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -20,9 +20,9 @@ class Tuning(C.Structure):
     """Mirror of `nv_tuning` (include/nanovllm_hip.h): launch-plan overrides, heuristics by default."""
     _fields_ = [("decode_target_waves", _i32), ("decode_chunk", _i32), ("decode_work_item", _i32),
                 ("decode_score_path", _i32), ("decode_mfma_depth", _i32), ("decode_single_launch", _i32),
-                ("prefill_split", _i32)]
+                ("prefill_split", _i32), ("prefill_kernel", _i32)]
     DEFAULTS = dict(decode_target_waves=0, decode_chunk=0, decode_work_item=-1, decode_score_path=-1,
-                    decode_mfma_depth=-1, decode_single_launch=-1, prefill_split=0)
+                    decode_mfma_depth=-1, decode_single_launch=-1, prefill_split=0, prefill_kernel=-1)
 
 
 # name -> (restype, argtypes); must mirror include/nanovllm_hip.h exactly

@@ -22,42 +22,9 @@
 // Semantics: flash_attn_varlen_func(..., causal=True, block_table=...) as called at
 // nanovllm/layers/attention.py:241-252 with metadata from nanovllm/engine/model_runner.py:85-119.
 #include "nv_common.h"
+#include "attn_prefill_shared.h"
 
 namespace nv {
-
-constexpr int kBN = 64;                     // keys per tile
-constexpr float kRunInit = -1.0e30f;        // finite initial running max (keeps exp2 NaN-free)
-constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 between rescales
-
-constexpr int kPartStride = kHeadDim + 4;    // fp32 per partial state: 128 acc + m + l + 2 pad
-
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-
-struct PrefillParams {
-    const uint4* q;
-    const uint4* k_cache;
-    const uint4* v_cache;
-    __bf16* o;
-    const int32_t* cu_q;
-    const int32_t* cu_k;
-    const int32_t* block_tables;
-    int B, max_blocks, H_q, H_kv, block_size;
-    int hpw;          // query heads per workgroup (divides G and 4)
-    int rows_per_wg;  // 32 * (4 / hpw)
-    int n_qtiles;     // ceil(max_seqlen_q / rows_per_wg)
-    int wg_per_pair;  // n_qtiles * (G / hpw): workgroups of one (sequence, kv head)
-    int n_pairs;      // B * H_kv
-    int64_t num_blocks;
-    int64_t q_stride_vec, o_stride;
-    float scale_log2;
-    int skip_single;
-    // key-range splitting (launches with too few workgroups for the chip)
-    float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states
-    int nsplit;           // 1: results are written directly
-    int tiles_per_split;  // 64-key tiles per split
-    int grid_base;        // workgroups per split (multiple of 8)
-};
 
 // LDS image of a [64 keys][128 dims] bf16 tile: 8-row x 32-column subtiles of 512 bytes,
 // with the 16-byte chunk inside a subtile row XOR-ed by bits 2..3 of the row.  Byte offset
@@ -424,24 +391,40 @@ struct PrefillShape {
     int nw, hpw, rows_per_wg, n_qtiles, wg_per_pair, n_pairs;
     int64_t grid_base;
     int nsplit, tiles_per_split;
+    bool hand_scheduled;   // attn_prefill_asm_kernel (64 query rows per wave, never split) instead of attn_prefill_kernel
 };
 
 // Workgroup shape and key-range split of a launch.  The key range is split only when the
 // launch would leave most CUs without a workgroup (one long sequence prefilled in chunks)
 // and every split still gets a few tiles.
-static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, int max_seqlen_k) {
-    PrefillShape sh;
+static void prefill_grid(PrefillShape& sh, int B, int H_q, int H_kv, int max_seqlen_q, int rows_per_wave) {
     const int G = H_q / H_kv;
     sh.nw = 4;
     sh.hpw = gcd_int(G, sh.nw);
-    sh.rows_per_wg = 32 * (sh.nw / sh.hpw);
+    sh.rows_per_wg = rows_per_wave * (sh.nw / sh.hpw);
     sh.n_qtiles = (max_seqlen_q + sh.rows_per_wg - 1) / sh.rows_per_wg;
     sh.wg_per_pair = sh.n_qtiles * (G / sh.hpw);
     sh.n_pairs = B * H_kv;
     sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+}
+
+static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, int max_seqlen_k) {
+    PrefillShape sh;
     const int tiles = (max_seqlen_k + kBN - 1) / kBN;
-    int ns = 1;
     const nv_tuning tn = tuning();
+    // The hand-scheduled kernel runs one workgroup per CU and never splits the key range: it takes the
+    // launches that fill the chip with 64-row waves (nv_tuning.prefill_kernel forces either kernel).
+    prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 64);
+    const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
+    sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : big_wgs >= 256;
+    if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
+    if (sh.hand_scheduled) {
+        sh.nsplit = 1;
+        sh.tiles_per_split = tiles > 0 ? tiles : 1;
+        return sh;
+    }
+    prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 32);
+    int ns = 1;
     if (tn.prefill_split > 0) {
         ns = tn.prefill_split;
     } else {
@@ -538,6 +521,10 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     const int64_t grid = sh.grid_base * sh.nsplit;
     NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
     hipStream_t st = (hipStream_t)stream;
+    if (sh.hand_scheduled) {
+        launch_prefill_asm(p, grid, st);
+        return check_launch("nv_attn_prefill_varlen(hand-scheduled)");
+    }
     hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
     int rc = check_launch("nv_attn_prefill_varlen");
     if (rc != NV_OK || sh.nsplit == 1) return rc;

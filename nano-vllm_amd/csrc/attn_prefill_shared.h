@@ -1,0 +1,46 @@
+// Declarations shared by the two prefill attention kernels (attn_prefill.hip, attn_prefill_asm.hip).
+#pragma once
+
+#include "nv_common.h"
+
+namespace nv {
+
+constexpr int kBN = 64;                     // keys per tile
+constexpr float kRunInit = -1.0e30f;        // finite initial running max (keeps exp2 NaN-free)
+constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 between rescales
+
+constexpr int kPartStride = kHeadDim + 4;    // fp32 per partial state: 128 acc + m + l + 2 pad
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct PrefillParams {
+    const uint4* q;
+    const uint4* k_cache;
+    const uint4* v_cache;
+    __bf16* o;
+    const int32_t* cu_q;
+    const int32_t* cu_k;
+    const int32_t* block_tables;
+    int B, max_blocks, H_q, H_kv, block_size;
+    int hpw;          // query heads per workgroup (divides G and 4)
+    int rows_per_wg;  // 32 * (4 / hpw)
+    int n_qtiles;     // ceil(max_seqlen_q / rows_per_wg)
+    int wg_per_pair;  // n_qtiles * (G / hpw): workgroups of one (sequence, kv head)
+    int n_pairs;      // B * H_kv
+    int64_t num_blocks;
+    int64_t q_stride_vec, o_stride;
+    float scale_log2;
+    int skip_single;
+    // key-range splitting (launches with too few workgroups for the chip)
+    float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states
+    int nsplit;           // 1: results are written directly
+    int tiles_per_split;  // 64-key tiles per split
+    int grid_base;        // workgroups per split (multiple of 8)
+};
+
+// hand-scheduled kernel for large launches (attn_prefill_asm.hip): one wave per SIMD, 64 query rows per wave
+void launch_prefill_asm(const PrefillParams& p, int64_t grid, hipStream_t st);
+int prefill_asm_max_tiles();
+
+}  // namespace nv

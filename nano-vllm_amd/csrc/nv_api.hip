@@ -5,7 +5,7 @@ namespace nv {
 
 static thread_local char g_err[512] = "";
 
-static const nv_tuning kDefaultTuning = {0, 0, -1, -1, -1, -1, 0};
+static const nv_tuning kDefaultTuning = {0, 0, -1, -1, -1, -1, 0, -1};
 static nv_tuning g_tuning = kDefaultTuning;
 
 nv_tuning tuning() { return g_tuning; }
@@ -32,7 +32,7 @@ extern "C" const char* nv_strerror(int code) {
     }
 }
 
-extern "C" int nv_abi_version(void) { return 3; }
+extern "C" int nv_abi_version(void) { return 4; }
 
 extern "C" int nv_set_tuning(const nv_tuning* t) {
     if (!t) {
@@ -42,7 +42,8 @@ extern "C" int nv_set_tuning(const nv_tuning* t) {
     NV_REQUIRE(t->decode_target_waves >= 0 && t->decode_chunk >= 0 && t->decode_chunk % 64 == 0 &&
                    t->prefill_split >= 0 && t->decode_work_item >= -1 && t->decode_work_item <= 1 &&
                    t->decode_score_path >= -1 && t->decode_score_path <= 1 && t->decode_mfma_depth >= -1 &&
-                   t->decode_mfma_depth <= 1 && t->decode_single_launch >= -1 && t->decode_single_launch <= 1,
+                   t->decode_mfma_depth <= 1 && t->decode_single_launch >= -1 && t->decode_single_launch <= 1 && t->prefill_kernel >= -1 &&
+                   t->prefill_kernel <= 1,
                NV_ERR_INVALID_ARG, "nv_set_tuning: field out of range");
     nv::g_tuning = *t;
     return NV_OK;

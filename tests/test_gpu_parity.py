@@ -408,6 +408,76 @@ def test_prefill_against_oracle(hip, H_q, H_kv, n_qs, n_ks):
     _attn_check(_run_attention(ops, pd, "mixed"), ref, "mixed")
 
 
+@pytest.mark.parametrize("H_q,H_kv", [(4, 1), (16, 8), (32, 8), (4, 4), (64, 8), (12, 4)])
+@pytest.mark.parametrize("n_qs,n_ks", [
+    ([64], [64]), ([64], [192]), ([256], [256]), ([70], [70]), ([5], [13]), ([3], [1]),
+    ([1, 31, 32, 33, 127, 128, 129], [1, 31, 32, 33, 127, 128, 129]),
+    ([512, 512, 300], [1024, 512, 812]),
+    ([64, 1, 200, 1], [64, 300, 456, 1]),
+    ([300], [2049]),
+])
+def test_prefill_hand_scheduled_kernel_against_oracle(hip, tuning, H_q, H_kv, n_qs, n_ks):
+    """The hand-scheduled kernel (one wave per SIMD, 64 rows per wave, software-pipelined asm loop), forced
+    for launches of any size: one tile, several tiles, masked diagonal and tail tiles, chunked prefill,
+    rows without any visible key, decode rows inside the launch, every head-group shape."""
+    _, ops = hip
+    bs = 256
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+    p = make_paged_problem(sum(n_ks) + 3 * H_q, n_qs, n_ks, H_q, H_kv, bs, nb)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    tuning(prefill_kernel=1)
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "prefill-hand")
+    _attn_check(_run_attention(ops, pd, "mixed"), ref, "mixed-hand")
+
+
+def test_prefill_hand_scheduled_kernel_rescale_and_nan_tails(hip, tuning):
+    """Side paths of the hand-scheduled loop: a late key with a much larger score (the running maximum
+    jumps: accumulator rescale), scores that rise steadily along the context (many rescales), NaN bit
+    patterns in the cache rows behind the end of a sequence (the tail tile re-reads its last valid row),
+    block size 64 and a strided q."""
+    _, ops = hip
+    tuning(prefill_kernel=1)
+    p = make_paged_problem(3, [512], [512], 4, 2, 256, 3)
+    blk = p["block_tables"][0, 1].item()
+    p["k_cache"][blk, 200] = (p["q"][511, 0] * 3).to(torch.bfloat16)[None, :].expand(2, -1)   # spike for query 511
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "hand-spike")
+    p = make_paged_problem(8, [700], [700], 8, 2, 256, 4)
+    g = torch.Generator().manual_seed(5)
+    u = torch.randn(128, generator=g)
+    p["q"] = (u[None, None, :] + 0.05 * torch.randn(700, 8, 128, generator=g)).bfloat16()
+    for j0 in range(0, 700, 256):
+        blk = p["block_tables"][0, j0 // 256].item()
+        j = torch.arange(j0, min(j0 + 256, 700), dtype=torch.float32)
+        rows = 6.0 * (j / 700)[:, None, None] * u[None, None, :] + 0.1 * torch.randn(len(j), 2, 128, generator=g)
+        p["k_cache"][blk, : len(j)] = rows.bfloat16()
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "hand-rising")
+    p = make_paged_problem(11, [5, 70, 257], [5, 70, 257], 16, 8, 256, 5)
+    nan = torch.tensor(float("nan")).bfloat16()
+    for b, n in enumerate([5, 70, 257]):
+        for j in range(n, ((n + 255) // 256) * 256):
+            blk = p["block_tables"][b, j // 256].item()
+            p["k_cache"][blk, j % 256] = nan
+            p["v_cache"][blk, j % 256] = nan
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "hand-nan-tail")
+    p = make_paged_problem(77, [100, 260], [164, 260], 8, 2, 64, 9)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    pd = to_dev(p)
+    T, H_q, D = p["q"].shape
+    wide = torch.zeros(T, H_q * D + 512, dtype=torch.bfloat16, device=DEV)
+    wide[:, :H_q * D] = pd["q"].view(T, -1)
+    pd["q"] = wide[:, :H_q * D].view(T, H_q, D)
+    _attn_check(_run_attention(ops, pd, "prefill"), ref, "hand-bs64-strided")
+
+
 def test_prefill_key_range_split_long_chunk(hip):
     """One long sequence prefilled in a chunk: too few workgroups for the chip, so the launch splits
     the key range over several workgroups and merges their states in a second launch."""
@@ -534,7 +604,8 @@ def test_full_size_decode_properties(hip):
     assert torch.equal(o, o2)
 
 
-def test_full_size_prefill_properties(hip):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_full_size_prefill_properties(hip, tuning, kernel):
     """Config-3 size (H 32/8, one 8192-token sequence, block 256) through size-independent properties:
     (1) the last 512-token chunk computed alone (keys 0..8191 cached; the key-range split path) equals
     rows 7680..8191 of the whole-prompt prefill (the unsplit path) within the tolerance; (2) V == const
@@ -545,6 +616,7 @@ def test_full_size_prefill_properties(hip):
     NB = n // bs
     p = make_paged_problem(5, [n], [n], H_q, H_kv, bs, NB, pad_cols=0)
     pd = to_dev(p)
+    tuning(prefill_kernel=kernel)        # 0: compiler-scheduled kernel (and its key-range split); 1: hand-scheduled
     full = _run_attention(ops, pd, "prefill")
     last = dict(pd, q=pd["q"][n - chunk:].contiguous(), cu_q=torch.tensor([0, chunk], dtype=torch.int32, device=DEV),
                 max_q=chunk)

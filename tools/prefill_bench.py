@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", default="")
+    ap.add_argument("--kernels", default="auto", help="comma list of auto,0,1 (nv_tuning.prefill_kernel: 0 compiler-scheduled, 1 hand-scheduled)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     dll = _lib.load(args.lib or None)
@@ -71,21 +72,31 @@ def main():
                                             stream)
             assert rc == 0, dll.nv_last_error()
 
-        launch()
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(args.rounds):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(args.iters):
-                launch()
-            b.record()
-            torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) / args.iters)
         f = flops(n_qs, n_ks, H_q)
-        med = statistics.median(ts)
-        print(f"{name:>22s}: {med*1e3:9.1f} us  {f/med/1e9:8.1f} TFLOP/s  ({100*f/med/1e9/2500:5.1f}% of 2.5 PF)  "
-              f"flops={f/1e9:.1f} G", flush=True)
+        kernels = args.kernels.split(",")
+        ts = {k: [] for k in kernels}
+        for rnd in range(args.rounds + 1):
+            for k in kernels:                      # interleaved rounds in one process
+                t = _lib.Tuning(**{**_lib.Tuning.DEFAULTS, **({} if k == "auto" else {"prefill_kernel": int(k)})})
+                assert dll.nv_set_tuning(t) == 0
+                need = dll.nv_attn_prefill_workspace_bytes(B, T, max(n_qs), max(n_ks), H_q, H_kv, D)
+                if need > ws.numel():
+                    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                launch()
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(args.iters):
+                    launch()
+                b.record()
+                torch.cuda.synchronize()
+                if rnd > 0:
+                    ts[k].append(a.elapsed_time(b) / args.iters)
+        dll.nv_set_tuning(None)
+        for k in kernels:
+            med = statistics.median(ts[k])
+            print(f"{name:>22s} kernel={k:>4s}: {med*1e3:9.1f} us  {f/med/1e9:8.1f} TFLOP/s  ({100*f/med/1e9/2500:5.1f}% of 2.5 PF)  "
+                  f"flops={f/1e9:.1f} G", flush=True)
 
 
 if __name__ == "__main__":
