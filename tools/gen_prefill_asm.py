@@ -176,6 +176,9 @@ def max_stream(buf):
     return out
 
 
+STATS: dict = {}
+
+
 def interleave(o: Out, mfmas, fillers, tag):
     """One MFMA, then its share of the fillers.  A filler is a string or (min_gap, string): the
     instruction may not be placed before MFMA number min_gap has been issued."""
@@ -184,6 +187,7 @@ def interleave(o: Out, mfmas, fillers, tag):
     total = len(items)
     pos = 0
     pending: list[tuple[int, str]] = []
+    STATS[tag] = (len(mfmas), total)
     for g, m in enumerate(mfmas):
         emit_mfma(o, m)
         want = (g + 1) * total // n_m - g * total // n_m
@@ -258,14 +262,14 @@ def mask_setup(o: Out, buf, tag):
 
 
 def dma_pieces(kind, slot, offregs):
-    """Four 1 KiB LDS-DMA pieces of this wave for a K or V tile whose 64-bit source base sits in
-    s[54:55]; the LDS destination of a piece goes through M0."""
-    out = []
+    """Four 1 KiB LDS-DMA pieces of this wave for a K or V tile whose 64-bit source base (minus 4096) sits
+    in s[54:55].  M0 holds the LDS address of the wave's first piece; piece i goes through the immediate
+    offset i * 1024, which the hardware adds to the LDS address AND to the global address: the per-lane
+    source offsets are stored as offset + 4096 - 1024 i (the 4096 keeps them non-negative)."""
+    dst = slot * SLOT + (V_OFF if kind == "V" else 0)
+    out = [f"s_add_u32 m0, s{S_PIECE}, {dst}", "s_nop 0"]
     for i in range(4):
-        dst = slot * SLOT + (V_OFF if kind == "V" else 0) + i * 1024
-        out.append(f"s_add_u32 m0, s{S_PIECE}, {dst}")
-        out.append("s_nop 0")
-        out.append(f"global_load_lds_dwordx4 v{offregs[i]}, s[54:55]")
+        out.append(f"global_load_lds_dwordx4 v{offregs[i]}, s[54:55] offset:{i * 1024}")
     return out
 
 
@@ -347,7 +351,7 @@ def dma_block(o_list, p, tag_o: Out, tag):
 # ---- sections ----------------------------------------------------------------------------------------
 def gen_prologue(o: Out):
     o.c("---- set-up: operands to fixed registers, lane parameters and Q fragments from LDS ----")
-    o.e(f"s_mov_b64 s[{S_KBASE}:{S_KBASE + 1}], %0")
+    o.e(f"s_mov_b64 s[{S_KBASE}:{S_KBASE + 1}], %0")     # operands 0, 1: cache bases (kv head folded in) minus 4096
     o.e(f"s_mov_b64 s[{S_VBASE}:{S_VBASE + 1}], %1")
     o.e(f"s_mov_b32 s{S_NT}, %2")
     o.e(f"s_mov_b32 s{S_C}, %3")
@@ -451,41 +455,33 @@ def gen_body(o: Out, p):
     o.label(f".Lpf_body{p}")
     mask_setup(o, p, tag)
     # ---- phase 1 ----
-    f1: list = []
-    f1 += [f"v_readfirstlane_b32 s{S_T0 + 2}, v252", f"v_readfirstlane_b32 s{S_T0 + 3}, v253",
-           f"v_readfirstlane_b32 s{S_T0 + 6}, v254", f"v_readfirstlane_b32 s{S_T0 + 7}, v255"]
     vr = v_reads(q)
     ex = exp_stream(q, 1)
-    # V(j) fetch (always), then K(j+2) when it exists: emitted as straight-line code before the phase
-    # (scalar branches inside the MFMA stream would split the schedule)
-    o.c(f"fetch V(j) and K(j+2) into slot {p}")
-    for ln in f1:
-        o.e(ln)
-    o.e(f"s_add_u32 s54, s{S_VBASE}, s{S_T0 + 6}")
-    o.e(f"s_addc_u32 s55, s{S_VBASE + 1}, s{S_T0 + 7}")
+    # V(j) and K(j+2) go to slot p.  The tile that holds the end of the sequence switches the wave's
+    # source offsets to the clamped set (rare, checked here: branches stay out of the MFMA stream).
+    # K(j+2) may lie behind the last tile: its table entry then repeats the last tile (a harmless fetch
+    # into a slot nobody reads again).
     tail_fix(o, S_J, DOFFV, f"{tag}_v")
-    dv = dma_pieces("V", p, DOFFV)
     o.e(f"s_add_u32 s{S_T0}, s{S_J}, 2")
-    dk_pre = [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}", f"s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
-    dk = dma_pieces("K", p, DOFFK)
-    # V pieces go out at once (s[54:55] is reused for K afterwards)
-    for ln in dv:
-        o.e(ln)
-    o.e(f"s_cmp_ge_u32 s{S_T0}, s{S_NT}")
-    o.e(f"s_cbranch_scc1 .Lpf_{tag}_nok")
     tail_fix(o, S_T0, DOFFK, f"{tag}_k")
-    for ln in dk_pre + dk:
-        o.e(ln)
-    o.label(f".Lpf_{tag}_nok")
+    dma = [f"v_readfirstlane_b32 s{S_T0 + 6}, v254", f"v_readfirstlane_b32 s{S_T0 + 7}, v255",
+           f"v_readfirstlane_b32 s{S_T0 + 2}, v252", f"v_readfirstlane_b32 s{S_T0 + 3}, v253",
+           f"s_add_u32 s54, s{S_VBASE}, s{S_T0 + 6}", f"s_addc_u32 s55, s{S_VBASE + 1}, s{S_T0 + 7}"]
+    dma += dma_pieces("V", p, DOFFV)
+    dma += [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}", f"s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
+    dma += dma_pieces("K", p, DOFFK)
     fill1: list = []
-    # merge: V reads early (they are needed at the start of phase 2), exponentials throughout
-    vi = 0
+    # merge: fetches first, V reads early (needed at the start of phase 2), exponentials throughout
+    vi = di = 0
     for k, x in enumerate(ex):
         fill1.append(x[1] if isinstance(x, tuple) else x)
+        if k % 2 == 1 and di < len(dma):
+            fill1.append(dma[di])
+            di += 1
         if k % 3 == 1 and vi < len(vr):
             fill1.append(vr[vi])
             vi += 1
-    fill1 += vr[vi:]
+    fill1 += dma[di:] + vr[vi:]
     interleave(o, qk_mfmas(p, f".Lpf_mm_{tag}"), fill1, tag + "p1")
     o.e("s_waitcnt lgkmcnt(0)")
     # ---- phase 2 ----
@@ -619,6 +615,8 @@ def main():
         f.write(clobbers() + "\n")
     n_inst = sum(1 for ln in text.splitlines() if ln.startswith("  ") and not ln.strip().startswith(";"))
     print(f"wrote {OUT}: {n_inst} instructions")
+    for tag, (nm, nf) in STATS.items():
+        print(f"  {tag}: {nm} MFMAs, {nf} fillers = {nf / nm:.2f} per gap")
 
 
 if __name__ == "__main__":
