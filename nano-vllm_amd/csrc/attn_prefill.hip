@@ -392,6 +392,7 @@ struct PrefillShape {
     int64_t grid_base;
     int nsplit, tiles_per_split;
     bool hand_scheduled;   // attn_prefill_asm_kernel (64 query rows per wave, never split) instead of attn_prefill_kernel
+    bool pair_items;       // its workgroups take two query tiles each (one from each end of the sequence)
 };
 
 // Workgroup shape and key-range split of a launch.  The key range is split only when the
@@ -418,7 +419,17 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
     sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : big_wgs >= 256;
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
+    sh.pair_items = false;
     if (sh.hand_scheduled) {
+        // two query tiles per workgroup (equal work for all workgroups of a sequence, half the fixed
+        // per-workgroup cost) while that still leaves two workgroups per CU
+        const int slots = (sh.n_qtiles + 1) / 2;
+        if ((int64_t)sh.n_pairs * slots * (sh.wg_per_pair / sh.n_qtiles) >= 512) {
+            sh.pair_items = true;
+            sh.wg_per_pair = slots * (sh.wg_per_pair / sh.n_qtiles);
+            sh.n_qtiles = slots;
+            sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+        }
         sh.nsplit = 1;
         sh.tiles_per_split = tiles > 0 ? tiles : 1;
         return sh;
@@ -512,6 +523,7 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.nsplit = sh.nsplit;
     p.tiles_per_split = sh.tiles_per_split;
     p.grid_base = (int)sh.grid_base;
+    p.pair_items = sh.pair_items ? 1 : 0;
     if (sh.nsplit > 1) {
         const int64_t need = (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
         NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,

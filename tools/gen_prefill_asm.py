@@ -40,16 +40,17 @@ def O(qb, d, i=0): return 64 * qb + 16 * d + i
 def Q(qb, s, w=0): return 128 + 32 * qb + 4 * s + w
 def K(kb, s, w=0): return 192 + 32 * kb + 4 * s + w
 
-M = [224, 225]      # running maximum per 32-row block (log2 domain, scale folded in)
-L = [226, 227]      # this lane's share of the running denominator
-AL = [228, 229]     # pending accumulator rescale factor
+NM = [224, 228]     # MINUS the running maximum per 32-row block (log2 domain, scale folded in), held twice
+                    # (v[NM:NM+1]) so that the packed fma reads it as a plain 64-bit operand
+L = [226, 246]      # this lane's share of the running denominator: two partial sums per block, v[L:L+1]
 TM = [230, 231]     # tile maximum (raw scores)
+AL = TM             # pending accumulator rescale factor: written by the side path after it has consumed the maximum
 KB = [232, 233]     # LDS read bases of the K fragments (k-step even / odd)
 VB = [234, 235]     # LDS read bases of the V^T fragments (rows +0 / +8)
 DOFFK = [236, 237, 238, 239]   # per-lane source offsets of this wave's four DMA pieces, K tiles
 DOFFV = [240, 241, 242, 243]   # the same for V tiles
 QPOS = [244, 245]   # last visible key of the lane's query row, minus 4 * (lane >> 5)
-ZERO, NINF, PADDR, STG = 246, 247, 248, 249
+PADDR, NINF = 248, 249
 T = [250, 251, 252, 253, 254, 255]   # temporaries; v[252:253] / v[254:255] carry tile-table entries across iterations
 
 # scalar registers (all listed as clobbers)
@@ -57,6 +58,13 @@ S_KBASE, S_VBASE = 36, 38      # 64-bit cache bases (kv head folded in)
 S_NT, S_J, S_C, S_TAIL, S_MASKFROM, S_MASKED, S_RESC, S_PIECE, S_STG, S_TBL = 40, 41, 42, 43, 44, 45, 46, 47, 48, 49
 S_T0 = 50                      # s50..s57 temporaries
 S_CMP = 60                     # s[60:67] compare results
+S_DESC, S_NITEMS, S_ITEM = 68, 69, 70      # LDS address of the wave's item descriptors, item count, current item
+S_QSEQ, S_OSEQ = 72, 74        # 64-bit: row 0 of this wave's query head in q / in o (of the sequence)
+S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
+S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
+S_SAVE = 82                    # s[82:83] saved exec
+S_ONES = 85                    # two bf16 ones
+S_LAST = 84                    # index of the next item while an epilogue prefetches for it
 
 # LDS layout (bytes)
 SLOT = 32768                   # one K tile (16 KiB) + one V tile (16 KiB)
@@ -64,14 +72,18 @@ V_OFF = 16384
 PARAM_OFF = 16384              # per-wave staging area: [16 Q fragments x 1 KiB][16 lane parameters x 256 B]
 MFMA = "v_mfma_f32_32x32x16_bf16"
 NEG_BIG = "0xf149f2ca"         # -1.0e30f
+POS_BIG = "0x7149f2ca"         # +1.0e30f
 EIGHT = "0x41000000"           # 8.0f
 
 
 class Out:
     def __init__(self):
         self.lines: list[str] = []
+        self.hot = False          # inside the loop bodies (ablations apply there only)
 
     def e(self, s: str):
+        if ABLATE and self.hot and ablated(s):
+            return
         self.lines.append("  " + s)
 
     def label(self, s: str):
@@ -137,22 +149,52 @@ def k_reads(slot):
 
 def exp_stream(buf, kb, with_cvt=True):
     """exp2(S * c - m) in place, row sums, packing to bf16 pairs for the S registers of key block kb.
-    Pattern per two values: fma a, exp a, fma b, exp b, add a, add b, cvt(a, b)."""
-    out = []
+    Per two values: one packed fma, two exponentials, one packed add into the two partial row sums, one
+    packing conversion.  The stream is skewed by one pair so that the two exponentials of a pair are never
+    neighbours and nothing reads an exponential in the instruction after it."""
+    pairs = []
     for qb in range(2):
         for i in range(0, 16, 2):
             ra, rb = S(buf, kb, qb, i), S(buf, kb, qb, i + 1)
-            out.append(f"v_fma_f32 v{T[0]}, v{ra}, s{S_C}, -v{M[qb]}")
-            out.append(f"v_exp_f32 v{ra}, v{T[0]}")
-            out.append(f"v_fma_f32 v{T[1]}, v{rb}, s{S_C}, -v{M[qb]}")
-            out.append(f"v_exp_f32 v{rb}, v{T[1]}")
-            out.append(f"v_add_f32 v{L[qb]}, v{L[qb]}, v{ra}")
-            out.append(f"v_add_f32 v{L[qb]}, v{L[qb]}, v{rb}")
+            # operands without half selection on the 64-bit register sources: a packed fma that picked the
+            # upper half of a register pair for its lower result gave wrong values in single 16-lane groups
+            # now and then (timing dependent); the scalar pair is read as one replicated dword
+            fma = f"v_pk_fma_f32 v[{ra}:{rb}], v[{ra}:{rb}], s[{S_C}:{S_C + 1}], v[{NM[qb]}:{NM[qb] + 1}] op_sel_hi:[1,0,1]"
+            add = f"v_pk_add_f32 v[{L[qb]}:{L[qb] + 1}], v[{L[qb]}:{L[qb] + 1}], v[{ra}:{rb}]"
+            if not PK_FMA:
+                fma = [f"v_fma_f32 v{ra}, v{ra}, s{S_C}, v{NM[qb]}", f"v_fma_f32 v{rb}, v{rb}, s{S_C}, v{NM[qb]}"]
+            if not PK_ADD:
+                add = [f"v_add_f32 v{L[qb]}, v{L[qb]}, v{ra}", f"v_add_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{rb}"]
+            cvt = None
             if with_cvt:
                 ks = 2 * kb + (i >> 3)
                 w = (i & 7) >> 1
-                out.append(("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}"))
-    return out
+                cvt = ("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}")
+                if DOT2:
+                    lr = L[qb] + ((i >> 1) & 1)
+                    add = ("cvt", f"v_dot2_f32_bf16 v{lr}, v{P(ks, qb, w)}, s{S_ONES}, v{lr}")
+            pairs.append((fma, f"v_exp_f32 v{ra}, v{ra}", f"v_exp_f32 v{rb}, v{rb}", add, cvt))
+    if DOT2:
+        pairs = [(f, ea, eb, c, a) for (f, ea, eb, a, c) in pairs]      # conversion first, then the dot
+    out = [pairs[0][0]]
+    for n, (fma, ea, eb, add, cvt) in enumerate(pairs):
+        out.append(ea)
+        if n + 1 < len(pairs):
+            out.append(pairs[n + 1][0])
+        elif n > 0:
+            out.append(pairs[n - 1][3])
+        out.append(eb)
+        if n > 0 and n + 1 < len(pairs):
+            out.append(pairs[n - 1][3])
+        if n > 0 and pairs[n - 1][4]:
+            out.append(pairs[n - 1][4])
+    out.append(pairs[-1][3])
+    if pairs[-1][4]:
+        out.append(pairs[-1][4])
+    flat = []
+    for x in out:
+        flat += x if isinstance(x, list) else [x]
+    return flat
 
 
 def max_stream(buf):
@@ -177,6 +219,37 @@ def max_stream(buf):
 
 
 STATS: dict = {}
+# placement knobs (experiments): MFMAs of phase 2 that carry the maxima; spacing of the V reads in phase 1
+# Measured on gfx950 inside this loop: v_pk_fma_f32 / v_pk_add_f32 cost more issue time than the two plain
+# instructions they replace (the 4 x 8192 case ran 12 % slower with both), so they stay off.
+PK_FMA = os.environ.get("PF_PKFMA", "0") == "1"
+PK_ADD = os.environ.get("PF_PKADD", "0") == "1"
+DOT2 = os.environ.get("PF_DOT2", "0") == "1"      # row sums from the packed bf16 pair: one dot instruction per pair
+N_HEAD = int(os.environ.get("PF_NHEAD", "12"))
+VR_MOD = tuple(int(x) for x in os.environ.get("PF_VRMOD", "2,0").split(","))
+# timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,lgkm
+ABLATE = set(filter(None, os.environ.get("PF_ABLATE", "").split(",")))
+
+
+def ablated(txt: str) -> bool:
+    op = txt.split()[0]
+    if "dma" in ABLATE and op.startswith("global_load_lds"):
+        return True
+    if "barrier" in ABLATE and op in ("s_barrier",):
+        return True
+    if "exp" in ABLATE and op in ("v_exp_f32", "v_fma_f32", "v_add_f32", "v_cvt_pk_bf16_f32"):
+        return True
+    if "max" in ABLATE and op in ("v_max3_f32",):
+        return True
+    if "vread" in ABLATE and op == "ds_read_b64_tr_b16":
+        return True
+    if "kread" in ABLATE and op == "ds_read_b128" and "a[19" in txt or "kread" in ABLATE and op == "ds_read_b128" and "a[2" in txt:
+        return True
+    if "mfma" in ABLATE and op.startswith("v_mfma"):
+        return True
+    if op.startswith("s_cbranch") and (".Lpf_slow" in txt or ".Lpf_resc" in txt):
+        return True          # every timing build skips the data-dependent side paths
+    return False
 
 
 def interleave(o: Out, mfmas, fillers, tag):
@@ -254,7 +327,7 @@ def mask_setup(o: Out, buf, tag):
                     key = kb * 32 + (i & 3) + 8 * (i >> 2)
                     blk.append(f"  v_cmp_ge_i32 s[{S_CMP + 2 * k}:{S_CMP + 2 * k + 1}], v{T[qb]}, {key}")
                 for k in range(4):
-                    blk.append(f"  v_cndmask_b32 v{S(buf, kb, qb, i0 + k)}, v{NINF}, v{ZERO}, "
+                    blk.append(f"  v_cndmask_b32 v{S(buf, kb, qb, i0 + k)}, v{NINF}, 0, "
                                f"s[{S_CMP + 2 * k}:{S_CMP + 2 * k + 1}]")
     blk.append("  s_nop 3")
     blk.append(f"  s_branch .Lpf_mask_{tag}_ret")
@@ -299,8 +372,8 @@ def table_lookup(o_list, tile_off_bytes_K, tile_off_bytes_V):
 def slow_max(o: Out, tag):
     """Decision of the deferred rescale: any row whose tile maximum exceeds the running one by more than
     2^8 sends the wave through the side path that raises the maxima and records the factors."""
-    o.e(f"v_fma_f32 v{T[0]}, v{TM[0]}, s{S_C}, -v{M[0]}")
-    o.e(f"v_fma_f32 v{T[1]}, v{TM[1]}, s{S_C}, -v{M[1]}")
+    o.e(f"v_fma_f32 v{T[0]}, v{TM[0]}, s{S_C}, v{NM[0]}")
+    o.e(f"v_fma_f32 v{T[1]}, v{TM[1]}, s{S_C}, v{NM[1]}")
     o.e(f"v_max_f32 v{T[0]}, v{T[0]}, v{T[1]}")
     o.e(f"v_cmp_lt_f32 vcc, {EIGHT}, v{T[0]}")
     o.e(f"s_cbranch_vccnz .Lpf_slow_{tag}")
@@ -308,12 +381,15 @@ def slow_max(o: Out, tag):
     blk = [f".Lpf_slow_{tag}:"]
     for qb in range(2):
         blk += [f"  v_mul_f32 v{T[0]}, s{S_C}, v{TM[qb]}",
-                f"  v_max_f32 v{T[0]}, v{M[qb]}, v{T[0]}",
-                f"  v_sub_f32 v{T[1]}, v{M[qb]}, v{T[0]}",
+                f"  v_sub_f32 v{T[0]}, 0, v{T[0]}",
+                f"  v_min_f32 v{T[0]}, v{NM[qb]}, v{T[0]}",          # minus the new maximum
+                f"  v_sub_f32 v{T[1]}, v{T[0]}, v{NM[qb]}",          # old maximum - new maximum <= 0
                 f"  v_exp_f32 v{AL[qb]}, v{T[1]}",
-                f"  v_mov_b32 v{M[qb]}, v{T[0]}",
+                f"  v_mov_b32 v{NM[qb]}, v{T[0]}",
+                f"  v_mov_b32 v{NM[qb] + 1}, v{T[0]}",
                 "  s_nop 0",
-                f"  v_mul_f32 v{L[qb]}, v{L[qb]}, v{AL[qb]}"]
+                f"  v_mul_f32 v{L[qb]}, v{L[qb]}, v{AL[qb]}",
+                f"  v_mul_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{AL[qb]}"]
     blk += [f"  s_mov_b32 s{S_RESC}, 1", f"  s_branch .Lpf_slow_{tag}_ret"]
     _ool.append(blk)
 
@@ -323,16 +399,17 @@ def rescale_check(o: Out, tag):
     o.e(f"s_cbranch_scc1 .Lpf_resc_{tag}")
     o.label(f".Lpf_resc_{tag}_ret")
     blk = [f".Lpf_resc_{tag}:", "  s_nop 15", "  s_nop 15"]
-    tmp = [T[0], T[1], TM[0], TM[1]]     # v[252:255] carry the next tiles' table entries at this point
+    tmp = [T[0], T[1]]     # v[252:255] carry the next tiles' table entries at this point
     for qb in range(2):
         for d in range(4):
-            for i0 in range(0, 16, 4):
-                for k in range(4):
+            for i0 in range(0, 16, 2):
+                for k in range(2):
                     blk.append(f"  v_accvgpr_read_b32 v{tmp[k]}, a{O(qb, d, i0 + k)}")
-                blk.append("  s_nop 0")
-                for k in range(4):
+                blk.append("  s_nop 1")
+                for k in range(2):
                     blk.append(f"  v_mul_f32 v{tmp[k]}, v{tmp[k]}, v{AL[qb]}")
-                for k in range(4):
+                blk.append("  s_nop 0")
+                for k in range(2):
                     blk.append(f"  v_accvgpr_write_b32 a{O(qb, d, i0 + k)}, v{tmp[k]}")
     blk += [f"  s_mov_b32 s{S_RESC}, 0", "  s_nop 7", f"  s_branch .Lpf_resc_{tag}_ret"]
     _ool.append(blk)
@@ -349,78 +426,143 @@ def dma_block(o_list, p, tag_o: Out, tag):
 
 
 # ---- sections ----------------------------------------------------------------------------------------
-def gen_prologue(o: Out):
-    o.c("---- set-up: operands to fixed registers, lane parameters and Q fragments from LDS ----")
-    o.e(f"s_mov_b64 s[{S_KBASE}:{S_KBASE + 1}], %0")     # operands 0, 1: cache bases (kv head folded in) minus 4096
-    o.e(f"s_mov_b64 s[{S_VBASE}:{S_VBASE + 1}], %1")
-    o.e(f"s_mov_b32 s{S_NT}, %2")
-    o.e(f"s_mov_b32 s{S_C}, %3")
-    o.e(f"s_mov_b32 s{S_TAIL}, %4")
-    o.e(f"s_mov_b32 s{S_MASKFROM}, %5")
-    o.e(f"s_mov_b32 s{S_PIECE}, %6")
-    o.e(f"s_mov_b32 s{S_STG}, %7")
-    o.e(f"s_mov_b32 s{S_TBL}, %8")
-    o.e(f"s_mov_b32 s{S_J}, 0")
+def q_fetch(o: Out, rw0_sreg, areg_base):
+    """Global loads of the 16 Q fragments of the item whose first row is in rw0_sreg straight into 64
+    accumulation registers from areg_base (fragment (qb, s) at + 32 qb + 4 s): source row
+    min(rw0 + 32 qb + r, n_q - 1), bytes 32 s + 16 h of the head row.  T[0], T[2], T[3] are used;
+    T[4] = lane & 31 and T[5] = 16 (lane >> 5) must be set (lane_consts)."""
+    for qb in range(2):
+        o.e(f"v_add_u32 v{T[0]}, s{rw0_sreg}, v{T[4]}")
+        if qb:
+            o.e(f"v_add_u32 v{T[0]}, 32, v{T[0]}")
+        o.e(f"v_min_u32 v{T[0]}, s{S_NQ1}, v{T[0]}")
+        o.e(f"v_mad_u32_u24 v{T[2 + qb]}, v{T[0]}, s{S_QSTR}, v{T[5]}")
+    for qb in range(2):
+        for sk in range(8):
+            r = areg_base + 32 * qb + 4 * sk
+            o.e(f"global_load_dwordx4 a[{r}:{r + 3}], v{T[2 + qb]}, s[{S_QSEQ}:{S_QSEQ + 1}] offset:{32 * sk}")
+
+
+def tile_fetch_const(o: Out, tile_const, kind, slot, offregs, tag, guard_nt):
+    """Straight-line fetch of tile `tile_const` (prologue of an item / prefetch for the next item)."""
+    if guard_nt:
+        o.e(f"s_cmp_le_u32 s{S_NT}, {tile_const}")
+        o.e(f"s_cbranch_scc1 .Lpf_skip_{tag}")
+    o.e(f"s_mov_b32 s{S_T0}, {tile_const}")
+    tail_fix(o, S_T0, offregs, tag)
+    o.e(f"v_mov_b32 v{T[0]}, s{S_TBL}")
+    o.e(f"ds_read_b64 v[252:253], v{T[0]} offset:{8 * tile_const}")
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e("s_nop 1")
+    o.e(f"v_readfirstlane_b32 s{S_T0 + 2}, v252")
+    o.e(f"v_readfirstlane_b32 s{S_T0 + 3}, v253")
+    base = S_VBASE if kind == "V" else S_KBASE
+    o.e(f"s_add_u32 s54, s{base}, s{S_T0 + 2}")
+    o.e(f"s_addc_u32 s55, s{base + 1}, s{S_T0 + 3}")
+    for ln in dma_pieces(kind, slot, offregs):
+        o.e(ln)
+    if guard_nt:
+        o.label(f".Lpf_skip_{tag}")
+
+
+def read_descriptor(o: Out, item_sreg, into_next=False):
+    """Item descriptor (8 dwords at s_desc + 32 item): nt, mask_from, rw0 + shift, rw0, rows."""
+    o.e(f"s_lshl_b32 s{S_T0}, s{item_sreg}, 5")
+    o.e(f"s_add_u32 s{S_T0}, s{S_T0}, s{S_DESC}")
+    o.e(f"v_mov_b32 v{T[0]}, s{S_T0}")
+    o.e(f"ds_read_b128 v[250:253], v{T[0]}")
+    o.e(f"ds_read_b32 v254, v{T[0]} offset:16")
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e("s_nop 1")
+    if into_next:
+        o.e(f"v_readfirstlane_b32 s{S_T0 + 1}, v253")            # rw0 of the next item
+    else:
+        o.e(f"v_readfirstlane_b32 s{S_NT}, v250")
+        o.e(f"v_readfirstlane_b32 s{S_MASKFROM}, v251")
+        o.e(f"v_readfirstlane_b32 s{S_ITEMBASE}, v252")
+        o.e(f"v_readfirstlane_b32 s{S_RW0}, v253")
+        o.e(f"v_readfirstlane_b32 s{S_ROWS}, v254")
+
+
+def lane_consts(o: Out):
+    """T[4] = lane & 31, T[5] = 16 * (lane >> 5) (temporaries: recomputed where needed)."""
+    o.e(f"v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0")
+    o.e(f"v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}")
+    o.e(f"v_and_b32 v{T[4]}, 31, v{T[0]}")
+    o.e(f"v_lshrrev_b32 v{T[5]}, 5, v{T[0]}")
+    o.e(f"v_lshlrev_b32 v{T[5]}, 4, v{T[5]}")
+
+
+def gen_setup(o: Out):
+    o.c("---- once per workgroup: operands to fixed registers, lane constants ----")
+    ops = [(S_KBASE, 64), (S_VBASE, 64), (S_C, 32), (S_TAIL, 32), (S_PIECE, 32), (S_STG, 32), (S_TBL, 32),
+           (S_DESC, 32), (S_NITEMS, 32), (S_QSEQ, 64), (S_OSEQ, 64), (S_QSTR, 32), (S_OSTR, 32), (S_NQ1, 32)]
+    for i, (r, bits) in enumerate(ops):
+        if bits == 64:
+            o.e(f"s_mov_b64 s[{r}:{r + 1}], %{i}")
+        else:
+            o.e(f"s_mov_b32 s{r}, %{i}")
+    o.e(f"s_mov_b32 s{S_ITEM}, 0")
     o.e(f"s_mov_b32 s{S_RESC}, 0")
+    o.e(f"s_mov_b32 s{S_ONES}, 0x3f803f80")
     o.e(f"v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0")
     o.e(f"v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}")
     o.e(f"v_lshlrev_b32 v{PADDR}, 2, v{T[0]}")
     o.e(f"v_add_u32 v{PADDR}, s{S_STG}, v{PADDR}")
-    o.e(f"v_lshlrev_b32 v{T[1]}, 4, v{T[0]}")
-    o.e(f"v_add_u32 v{T[1]}, s{S_STG}, v{T[1]}")
-    plist = [KB[0], KB[1], VB[0], VB[1]] + DOFFK
-    for pi, r in enumerate(plist):
+    for pi, r in enumerate([KB[0], KB[1], VB[0], VB[1]]):
         o.e(f"ds_read_b32 v{r}, v{PADDR} offset:{PARAM_OFF + pi * 256}")
+    o.e(f"v_mov_b32 v{NINF}, 0xff800000")
+    o.c("first item: its descriptor, its Q fragments, tiles 0 and 1")
+    read_descriptor(o, S_ITEM)
+    lane_consts(o)
+    q_fetch(o, S_RW0, Q(0, 0))
+
+
+def gen_item_prologue(o: Out):
+    """Start of an item.  On entry: descriptor scalars loaded, Q fragments of the item in flight or landed."""
+    o.label(".Lpf_item")
     for i in range(4):
+        o.e(f"ds_read_b32 v{DOFFK[i]}, v{PADDR} offset:{PARAM_OFF + (4 + i) * 256}")
         o.e(f"ds_read_b32 v{DOFFV[i]}, v{PADDR} offset:{PARAM_OFF + (4 + i) * 256}")
     o.e(f"ds_read_b32 v{QPOS[0]}, v{PADDR} offset:{PARAM_OFF + 12 * 256}")
     o.e(f"ds_read_b32 v{QPOS[1]}, v{PADDR} offset:{PARAM_OFF + 13 * 256}")
-    o.e(f"ds_read_b32 v{STG}, v{PADDR} offset:{PARAM_OFF + 14 * 256}")
+    o.e(f"s_mov_b32 s{S_J}, 0")
     for qb in range(2):
-        for s in range(8):
-            o.e(f"ds_read_b128 {rng('a', Q(qb, s), 4)}, v{T[1]} offset:{(qb * 8 + s) * 1024}")
-    o.e(f"v_mov_b32 v{ZERO}, 0")
-    o.e(f"v_mov_b32 v{NINF}, 0xff800000")
-    for qb in range(2):
-        o.e(f"v_mov_b32 v{M[qb]}, {NEG_BIG}")
+        o.e(f"v_mov_b32 v{NM[qb]}, {POS_BIG}")
+        o.e(f"v_mov_b32 v{NM[qb] + 1}, {POS_BIG}")
         o.e(f"v_mov_b32 v{L[qb]}, 0")
-        o.e(f"v_mov_b32 v{AL[qb]}, 1.0")
+        o.e(f"v_mov_b32 v{L[qb] + 1}, 0")
     for i in range(128):
         o.e(f"v_accvgpr_write_b32 a{i}, 0")
     o.e("s_waitcnt lgkmcnt(0)")
-
-    o.c("---- tile 0: fetch K0, V0 (slot 0) and K1 (slot 1), read K0 into registers, fetch K2 ----")
-
-    def fetch(tile_const, kind, slot, offregs, tag, guard_nt):
-        if guard_nt:
-            o.e(f"s_cmp_le_u32 s{S_NT}, {tile_const}")
-            o.e(f"s_cbranch_scc1 .Lpf_pro_skip_{tag}")
-        o.e(f"s_mov_b32 s{S_T0}, {tile_const}")
-        tail_fix(o, S_T0, offregs, f"pro_{tag}")
-        o.e(f"v_mov_b32 v{T[0]}, s{S_TBL}")
-        o.e(f"ds_read_b64 v[252:253], v{T[0]} offset:{8 * tile_const}")
-        o.e("s_waitcnt lgkmcnt(0)")
-        o.e("s_nop 1")
-        o.e(f"v_readfirstlane_b32 s{S_T0 + 2}, v252")
-        o.e(f"v_readfirstlane_b32 s{S_T0 + 3}, v253")
-        base = S_VBASE if kind == "V" else S_KBASE
-        o.e(f"s_add_u32 s54, s{base}, s{S_T0 + 2}")
-        o.e(f"s_addc_u32 s55, s{base + 1}, s{S_T0 + 3}")
-        for ln in dma_pieces(kind, slot, offregs):
-            o.e(ln)
-        if guard_nt:
-            o.label(f".Lpf_pro_skip_{tag}")
-
-    fetch(0, "K", 0, DOFFK, "k0", False)
-    fetch(0, "V", 0, DOFFV, "v0", False)
-    fetch(1, "K", 1, DOFFK, "k1", True)
+    for qb in range(2):
+        o.e(f"v_add_u32 v{QPOS[qb]}, s{S_ITEMBASE}, v{QPOS[qb]}")
+    # tiles 0, 1 of the first item are fetched here; later items had them prefetched by the item before
+    o.e(f"s_cmp_lg_u32 s{S_ITEM}, 0")
+    o.e("s_cbranch_scc1 .Lpf_prefetched")
+    tile_fetch_const(o, 0, "K", 0, DOFFK, "pro_k0", False)
+    tile_fetch_const(o, 0, "V", 0, DOFFV, "pro_v0", False)
+    tile_fetch_const(o, 1, "K", 1, DOFFK, "pro_k1", False)
     o.e("s_waitcnt vmcnt(0)")
+    o.e("s_branch .Lpf_fetched")
+    o.label(".Lpf_prefetched")
+    o.c("the item before fetched tiles 0 / 1 of this item and loaded its Q fragments into the K registers")
+    o.e("s_waitcnt vmcnt(0)")
+    for i0 in range(0, 64, 4):
+        for k in range(4):
+            o.e(f"v_accvgpr_read_b32 v{T[k]}, a{K(0, 0) + i0 + k}")
+        o.e("s_nop 0")
+        for k in range(4):
+            o.e(f"v_accvgpr_write_b32 a{Q(0, 0) + i0 + k}, v{T[k]}")
+    o.label(".Lpf_fetched")
     o.e("s_barrier")
+    o.e(f"s_cmp_eq_u32 s{S_NT}, 0")
+    o.e("s_cbranch_scc1 .Lpf_fin")
     for ln in k_reads(0):
         o.e(ln)
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_barrier")
-    fetch(2, "K", 0, DOFFK, "k2", True)
+    tile_fetch_const(o, 2, "K", 0, DOFFK, "pro_k2", False)
     mask_setup(o, 0, "pro")
     for m in qk_mfmas(0, ".Lpf_mm_pro"):
         emit_mfma(o, m)
@@ -431,7 +573,9 @@ def gen_prologue(o: Out):
         o.e(ln)
     for qb in range(2):
         o.e(f"v_mul_f32 v{T[0]}, s{S_C}, v{TM[qb]}")
-        o.e(f"v_max_f32 v{M[qb]}, {NEG_BIG}, v{T[0]}")
+        o.e(f"v_sub_f32 v{T[0]}, 0, v{T[0]}")
+        o.e(f"v_min_f32 v{NM[qb]}, {POS_BIG}, v{T[0]}")
+        o.e(f"v_mov_b32 v{NM[qb] + 1}, v{NM[qb]}")
     for ln in k_reads(1):
         o.e(ln)
     for x in exp_stream(0, 0):
@@ -478,7 +622,7 @@ def gen_body(o: Out, p):
         if k % 2 == 1 and di < len(dma):
             fill1.append(dma[di])
             di += 1
-        if k % 3 == 1 and vi < len(vr):
+        if k % VR_MOD[0] == VR_MOD[1] and vi < len(vr):
             fill1.append(vr[vi])
             vi += 1
     fill1 += dma[di:] + vr[vi:]
@@ -504,7 +648,7 @@ def interleave_phase2(o: Out, p, q, head, rest_kreads, tag):
     """Phase 2 is emitted in two parts because the rescale decision (a branch) sits between the maxima and
     the exponentials: MFMAs 0..n_head-1 carry the maxima, the rest carry exponentials / packing."""
     pv = pv_mfmas()
-    n_head = 9
+    n_head = N_HEAD
     interleave(o, pv[:n_head], head, tag + "p2a")
     slow_max(o, tag)
     tail: list = []
@@ -536,13 +680,32 @@ def interleave_phase2(o: Out, p, q, head, rest_kreads, tag):
 
 
 def gen_epilogue(o: Out, qbuf):
-    """After the last tile (which sits in buffer qbuf): finish its softmax, read its V, multiply."""
+    """After the last tile of an item (it sits in buffer qbuf): finish its softmax, read its V; then every
+    wave is done with the tile ring, so tiles 0 / 1 of the NEXT item are fetched while the last products
+    and the output stores run."""
     o.label(f".Lpf_epi{qbuf}")
     for ln in v_reads(qbuf):
         o.e(ln)
     for x in exp_stream(qbuf, 1):
         o.e(x[1] if isinstance(x, tuple) else x)
     o.e("s_waitcnt lgkmcnt(0)")
+    o.e("s_barrier")
+    o.e(f"s_add_u32 s{S_LAST}, s{S_ITEM}, 1")
+    o.e(f"s_cmp_ge_u32 s{S_LAST}, s{S_NITEMS}")
+    o.e(f"s_cbranch_scc1 .Lpf_epi{qbuf}_nonext")
+    o.c("source offsets back to the unclamped set, then K0, V0 -> slot 0, K1 -> slot 1 of the next item")
+    for i in range(4):
+        o.e(f"ds_read_b32 v{DOFFK[i]}, v{PADDR} offset:{PARAM_OFF + (4 + i) * 256}")
+        o.e(f"ds_read_b32 v{DOFFV[i]}, v{PADDR} offset:{PARAM_OFF + (4 + i) * 256}")
+    o.e("s_waitcnt lgkmcnt(0)")
+    tile_fetch_const(o, 0, "K", 0, DOFFK, f"epi{qbuf}_k0", False)
+    tile_fetch_const(o, 0, "V", 0, DOFFV, f"epi{qbuf}_v0", False)
+    tile_fetch_const(o, 1, "K", 1, DOFFK, f"epi{qbuf}_k1", False)
+    o.c("Q fragments of the next item -> the K fragment registers (dead until the next item's first tile)")
+    read_descriptor(o, S_LAST, into_next=True)
+    lane_consts(o)
+    q_fetch(o, S_T0 + 1, K(0, 0))
+    o.label(f".Lpf_epi{qbuf}_nonext")
     o.e("s_nop 3")
     for m in pv_mfmas():
         o.e(m)
@@ -555,6 +718,8 @@ def gen_finish(o: Out):
     o.e("s_nop 15")
     o.e("s_nop 15")
     for qb in range(2):
+        o.e(f"v_add_f32 v{L[qb]}, v{L[qb]}, v{L[qb] + 1}")
+    for qb in range(2):
         o.e(f"v_mov_b32 v{T[qb]}, v{L[qb]}")
     o.e("s_nop 1")
     for qb in range(2):
@@ -566,7 +731,13 @@ def gen_finish(o: Out):
         o.e(f"v_cmp_lt_f32 vcc, 0, v{L[qb]}")
         o.e("s_nop 1")
         o.e(f"v_cndmask_b32 v{AL[qb]}, 0, v{AL[qb]}, vcc")
-    o.c("O^T -> bf16 rows in the wave's staging area: row qb*32 + (lane & 31), 272-byte row stride")
+    o.c("O^T -> bf16 rows in the wave's staging area (row qb*32 + (lane & 31), 272-byte row stride), then")
+    o.c("whole 256-byte row segments to memory, 4 rows per store instruction; rows behind the sequence end are masked")
+    lane_consts(o)                                                  # T[0] lane, T[4] = r, T[5] = 16 h
+    o.e(f"v_lshrrev_b32 v{T[5]}, 1, v{T[5]}")                       # 8 h
+    o.e(f"s_movk_i32 s{S_T0 + 4}, 272")
+    o.e(f"v_mad_u32_u24 v{QPOS[0]}, v{T[4]}, s{S_T0 + 4}, v{T[5]}")
+    o.e(f"v_add_u32 v{QPOS[0]}, s{S_STG}, v{QPOS[0]}")              # staging write address of the lane
     for qb in range(2):
         for d in range(4):
             for g in range(4):
@@ -578,15 +749,48 @@ def gen_finish(o: Out):
                 o.e(f"v_cvt_pk_bf16_f32 v{T[4]}, v{T[0]}, v{T[1]}")
                 o.e(f"v_cvt_pk_bf16_f32 v{T[5]}, v{T[2]}, v{T[3]}")
                 o.e("s_nop 0")
-                o.e(f"ds_write_b64 v{STG}, v[{T[4]}:{T[5]}] offset:{qb * 32 * 272 + d * 64 + g * 16}")
+                o.e(f"ds_write_b64 v{QPOS[0]}, v[{T[4]}:{T[5]}] offset:{qb * 32 * 272 + d * 64 + g * 16}")
+    o.e(f"s_mul_i32 s{S_T0}, s{S_RW0}, s{S_OSTR}")
+    o.e(f"s_mul_hi_u32 s{S_T0 + 1}, s{S_RW0}, s{S_OSTR}")
+    o.e(f"s_add_u32 s{S_T0 + 2}, s{S_OSEQ}, s{S_T0}")
+    o.e(f"s_addc_u32 s{S_T0 + 3}, s{S_OSEQ + 1}, s{S_T0 + 1}")
+    o.e(f"v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0")
+    o.e(f"v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}")
+    o.e(f"v_lshrrev_b32 v{T[1]}, 4, v{T[0]}")                       # row inside a group of 4
+    o.e(f"v_and_b32 v{T[2]}, 15, v{T[0]}")
+    o.e(f"v_lshlrev_b32 v{T[2]}, 4, v{T[2]}")                       # 16-byte piece of the row
+    o.e(f"v_mad_u32_u24 v{T[3]}, v{T[1]}, s{S_T0 + 4}, v{T[2]}")
+    o.e(f"v_add_u32 v{T[3]}, s{S_STG}, v{T[3]}")                    # staging read address
+    o.e(f"v_mad_u32_u24 v{T[4]}, v{T[1]}, s{S_OSTR}, v{T[2]}")      # global offset of the lane's piece, group 0
+    o.e(f"s_lshl_b32 s{S_T0 + 5}, s{S_OSTR}, 2")                    # 4 rows further
     o.e("s_waitcnt lgkmcnt(0)")
+    for it in range(16):
+        o.e(f"ds_read_b128 v[{4 * it}:{4 * it + 3}], v{T[3]} offset:{it * 4 * 272}")
+    for it in range(16):
+        o.e(f"s_sub_i32 s{S_T0}, s{S_ROWS}, {4 * it}")
+        o.e(f"v_cmp_gt_i32 vcc, s{S_T0}, v{T[1]}")
+        o.e(f"s_waitcnt lgkmcnt({15 - it})")
+        o.e(f"s_and_saveexec_b64 s[{S_SAVE}:{S_SAVE + 1}], vcc")
+        o.e(f"global_store_dwordx4 v{T[4]}, v[{4 * it}:{4 * it + 3}], s[{S_T0 + 2}:{S_T0 + 3}]")
+        o.e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
+        o.e(f"v_add_u32 v{T[4]}, s{S_T0 + 5}, v{T[4]}")
+    o.c("next item")
+    o.e(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, 1")
+    o.e(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
+    o.e("s_cbranch_scc1 .Lpf_done")
+    read_descriptor(o, S_ITEM)
+    o.e("s_branch .Lpf_item")
+    o.label(".Lpf_done")
 
 
 def generate() -> str:
     o = Out()
-    gen_prologue(o)
+    gen_setup(o)
+    gen_item_prologue(o)
+    o.hot = True
     gen_body(o, 1)
     gen_body(o, 0)
+    o.hot = False
     gen_epilogue(o, 0)
     gen_epilogue(o, 1)
     gen_finish(o)
@@ -598,7 +802,7 @@ def generate() -> str:
 
 
 def clobbers() -> str:
-    regs = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(36, 68)]
+    regs = [f"v{i}" for i in range(256)] + [f"a{i}" for i in range(256)] + [f"s{i}" for i in range(36, 86)]
     regs += ["vcc", "scc", "memory"]
     return ", ".join(f'"{r}"' for r in regs)
 

@@ -29,6 +29,9 @@ CASES = [
     ([300], [2049], 4, 4),
     ([3], [1], 4, 2),
     ([2048], [2048], 8, 1),
+    # two query tiles per workgroup (>= 512 workgroups): even and odd tile counts, ragged, chunked
+    ([1024] * 16, [1024] * 16, 16, 2),
+    ([960, 1000, 64, 70] * 4, [960, 1300, 64, 326] * 4, 16, 2),
 ]
 
 

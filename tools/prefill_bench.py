@@ -22,6 +22,11 @@ CASES = {
     "b16_n2048_h32": ([2048] * 16, [2048] * 16, 32, 8),
     "b4_n8192_h32": ([8192] * 4, [8192] * 4, 32, 8),
     "b16_n2048_h64": ([2048] * 16, [2048] * 16, 64, 8),
+    # per-workgroup cost probes: 4096 workgroups of the hand-scheduled kernel with 1 / 2 / 4 tiles each
+    "wg_probe_1tile": ([64] * 512, [64] * 512, 32, 8),
+    "wg_probe_2tile": ([64] * 512, [128] * 512, 32, 8),
+    "wg_probe_4tile": ([64] * 512, [256] * 512, 32, 8),
+    "wg_probe_8tile": ([64] * 512, [512] * 512, 32, 8),
 }
 
 
