@@ -55,7 +55,7 @@ typedef struct nv_tuning {
     int decode_work_item;     /* -1 = heuristic; 0 = one wave per work item; 1 = one workgroup            */
     int decode_score_path;    /* -1 = heuristic; 0 = VALU scores for H_q/H_kv = 4, 8; 1 = MFMA scores     */
     int decode_mfma_depth;    /* -1 = heuristic; 0 / 1 = tiles prefetched ahead in the MFMA-score kernel  */
-    int decode_single_launch; /* -1 = heuristic; 0 = separate merge launch; 1 = last-arriver merge        */
+    int decode_single_launch; /* -1, 0 = split sequences combined by a second launch; 1 = inside the launch */
     int prefill_split;        /* 0 = heuristic; > 0: forced number of key-range splits                    */
     int prefill_kernel;       /* -1 = heuristic; 0 = compiler-scheduled kernel; 1 = hand-scheduled kernel  */
 } nv_tuning;

@@ -59,6 +59,15 @@ __device__ __forceinline__ uint4 kv_load(const uint4* p) {
 #endif
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte write-through store (sc1): the bytes go to memory instead of staying dirty in this XCD's L2.
+// The trailing s_nop keeps the compiler's next instruction off the data registers until the store has
+// read them.  The compiler does not count this store: drain with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void store16_wt(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 struct DecodeParams {
     const uint4* q;
     const uint4* k_cache;
@@ -68,6 +77,7 @@ struct DecodeParams {
     const int32_t* cu_k;
     const int32_t* block_tables;
     float* part;  // [B, H_q, nsplit, kPartStride]
+    int* tickets; // [B, H_kv] arrival counters of the in-launch combine (zero before the launch), or null
     int B, max_blocks, H_kv, block_size;
     int chunk, nsplit;
     int G;  // query heads per kv head
@@ -78,6 +88,7 @@ struct DecodeParams {
 
 // Final state of one (sequence, query head, key chunk) held by 16 lanes (lane c: dims 8c..8c+7):
 // written as the bf16 output when the sequence is not split, else as an fp32 partial state.
+template <bool TK>
 __device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq, int split, int tq, int c,
                                             float m, float l, const float (&a)[8]) {
     if (p.nsplit == 1) {
@@ -91,12 +102,21 @@ __device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq
     } else {
         const int H_q = p.H_kv * p.G;
         float* dst = p.part + (((int64_t)b * H_q + hq) * p.nsplit + split) * kPartStride;
-        float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
-        d4[0] = make_float4(a[0], a[1], a[2], a[3]);
-        d4[1] = make_float4(a[4], a[5], a[6], a[7]);
-        if (c == 0) {
-            dst[kHeadDim] = m;
-            dst[kHeadDim + 1] = l;
+        if (TK) {
+            // in-launch combine: another workgroup reads this state before the launch ends, so the stores
+            // are write-through (they leave the XCD's L2 for memory; the storing wave drains them before
+            // it signals) and every 16-byte store covers whole elements of the state
+            store16_wt(dst + 8 * c, f32x4{a[0], a[1], a[2], a[3]});
+            store16_wt(dst + 8 * c + 4, f32x4{a[4], a[5], a[6], a[7]});
+            if (c == 0) store16_wt(dst + kHeadDim, f32x4{m, l, 0.f, 0.f});
+        } else {
+            float4* d4 = reinterpret_cast<float4*>(dst + 8 * c);
+            d4[0] = make_float4(a[0], a[1], a[2], a[3]);
+            d4[1] = make_float4(a[4], a[5], a[6], a[7]);
+            if (c == 0) {
+                dst[kHeadDim] = m;
+                dst[kHeadDim + 1] = l;
+            }
         }
     }
 }
@@ -104,7 +124,7 @@ __device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq
 // Workgroup-split form: the kDecWaves waves of a workgroup each streamed a quarter of one
 // (sequence, kv head, chunk); their states meet in LDS and wave w finishes heads w, w+4, ...
 // sm: [kDecWaves][G][kPartStride] floats.  Every wave of the workgroup must call this.
-template <int G>
+template <int G, bool TK>
 __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm, int wave, int lane, int b, int h,
                                                int split, int tq, const float (&m)[G], const float (&l)[G],
                                                const float (&acc)[G][8]) {
@@ -140,16 +160,132 @@ __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm,
             a[4] += y.x * f; a[5] += y.y * f; a[6] += y.z * f; a[7] += y.w * f;
             ls += src[kHeadDim + 1] * f;
         }
-        store_state(p, b, h * p.G + g, split, tq, c, mm, ls, a);
+        store_state<TK>(p, b, h * p.G + g, split, tq, c, mm, ls, a);
     }
+}
+
+// ---- in-launch combine of split sequences --------------------------------------------------------
+// With p.tickets set, the work item that stores the LAST partial state of a (sequence, kv head) also
+// combines all of them and writes the output rows, so a split launch needs no second kernel.
+// Hand-off between workgroups (any placement over the XCDs): write-through partial stores -> every
+// storing wave drains its stores -> (workgroup items: barrier) -> one lane: relaxed agent-scope add on the
+// pair's counter; the item that draws ns - 1 runs one agent-scope acquire and then reads every partial
+// with plain vector loads.  That item puts the counter back to zero for the next launch.
+// (Plain stores behind an agent-scope release in every item measured 1.5x slower for the whole launch:
+// the release writes back the XCD's whole L2 while every other wave is streaming through it.)
+
+// One 32-lane group walks partial states s0, s0 + step, ... of one (sequence, query head); lane d4 holds
+// dims 4 d4 .. 4 d4 + 3.  Online form: one pass, every load independent of the others.
+__device__ __forceinline__ void merge_walk(const float* base, int s0, int step, int ns, int d4, float& mm,
+                                           float& den, float4& num) {
+    mm = kNegBig;
+    den = 0.f;
+    num = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int s = s0; s < ns; s += step) {
+        const float2 ml = *reinterpret_cast<const float2*>(base + s * kPartStride + kHeadDim);
+        const float4 a = *reinterpret_cast<const float4*>(base + s * kPartStride + 4 * d4);
+        const float mn = fmaxf(mm, ml.x);
+        const float fo = __builtin_amdgcn_exp2f(mm - mn), fn = __builtin_amdgcn_exp2f(ml.x - mn);
+        num.x = num.x * fo + a.x * fn;
+        num.y = num.y * fo + a.y * fn;
+        num.z = num.z * fo + a.z * fn;
+        num.w = num.w * fo + a.w * fn;
+        den = den * fo + ml.y * fn;
+        mm = mn;
+    }
+}
+
+__device__ __forceinline__ void merge_store_row(const DecodeParams& p, int tq, int hq, int d4, float den,
+                                                const float4& num) {
+    const float r = den > 0.f ? 1.0f / den : 0.f;
+    uint2 w;
+    w.x = pack_bf16(num.x * r, num.y * r);
+    w.y = pack_bf16(num.z * r, num.w * r);
+    __bf16* o = reinterpret_cast<__bf16*>(p.o) + (int64_t)tq * p.o_stride_vec * 8 + hq * kHeadDim;
+    *reinterpret_cast<uint2*>(o + 4 * d4) = w;
+}
+
+// Arrival of one work item at its pair's counter; true for the item that has to combine.  `leader` is
+// one lane of the item; every wave of the item that stored partial states has drained them already
+// (and, for a workgroup item, passed a barrier after that).
+__device__ __forceinline__ int ticket_arrive(int* ticket) {
+    return __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void ticket_acquire_and_reset(int* ticket) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave combines the partial states of query heads g0, g0 + gstep, ... of kv head h: its two halves walk
+// the even and the odd states, lane (lane & 31) holds 4 dims.
+__device__ __forceinline__ void wave_merge_heads(const DecodeParams& p, int b, int h, int tq, int ns, int lane,
+                                                 int g0, int gstep) {
+    const int H_q = p.H_kv * p.G;
+    const int grp = lane >> 5, d4 = lane & 31;
+    for (int g = g0; g < p.G; g += gstep) {
+        const int hq = h * p.G + g;
+        const float* base = p.part + ((int64_t)b * H_q + hq) * p.nsplit * kPartStride;
+        float mm, den;
+        float4 num;
+        merge_walk(base, grp, 2, ns, d4, mm, den, num);
+        const float mo = __shfl_xor(mm, 32);
+        const float mn = fmaxf(mm, mo);
+        const float f = __builtin_amdgcn_exp2f(mm - mn);
+        num.x *= f; num.y *= f; num.z *= f; num.w *= f;
+        den *= f;
+        num.x += __shfl_xor(num.x, 32);
+        num.y += __shfl_xor(num.y, 32);
+        num.z += __shfl_xor(num.z, 32);
+        num.w += __shfl_xor(num.w, 32);
+        den += __shfl_xor(den, 32);
+        if (grp == 0) merge_store_row(p, tq, hq, d4, den, num);
+    }
+}
+
+// Work item = one wave.  All 64 lanes call this after the wave's partial stores.
+__device__ __forceinline__ void wave_ticket_merge(const DecodeParams& p, int b, int h, int tq, int n_k, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int ns = (n_k + p.chunk - 1) / p.chunk;
+    ns = ns < 1 ? 1 : ns;
+    int* ticket = p.tickets + (int64_t)b * p.H_kv + h;
+    int old = 0;
+    if (lane == 0) old = ticket_arrive(ticket);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != ns - 1) return;
+    if (lane == 0) ticket_acquire_and_reset(ticket);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wave_merge_heads(p, b, h, tq, ns, lane, 0, 1);
+}
+
+// Work item = workgroup of kDecWaves waves.  Every thread calls this after wg_merge_store; flag is one
+// LDS word.  The waves of the combining workgroup take the query heads in turn.
+__device__ __forceinline__ void wg_ticket_merge(const DecodeParams& p, int* flag, int b, int h, int tq, int n_k,
+                                                int wave, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int ns = (n_k + p.chunk - 1) / p.chunk;
+    ns = ns < 1 ? 1 : ns;
+    int* ticket = p.tickets + (int64_t)b * p.H_kv + h;
+    if (threadIdx.x == 0) *flag = ticket_arrive(ticket);
+    __syncthreads();
+    const int old = *flag;
+    if (old != ns - 1) return;   // uniform over the workgroup
+    if (threadIdx.x == 0) ticket_acquire_and_reset(ticket);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    wave_merge_heads(p, b, h, tq, ns, lane, wave, kDecWaves);
 }
 
 // kDepth = tiles (8 KiB per wave each) kept in flight ahead of the one being consumed.
 // WGS = false: every wave is its own work item.  WGS = true (launches with few (sequence, head)
 // pairs): the workgroup is one work item, its waves take a quarter of the chunk each and merge
 // through LDS, which replaces a 4-fold deeper global split (partial states and merge work / 4).
-template <int G, bool ALIGNED, int kDepth, bool WGS>
+template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const DecodeParams p) {
+    // workgroup items: the waves' states (its first word later carries the arrival number of the in-launch combine)
     __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -318,12 +454,15 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     }
 
     if (WGS) {
-        wg_merge_store<G>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        if (TK) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
         return;
     }
-    if (kq != 0) return;
+    if (kq == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) store_state(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
+        for (int g = 0; g < G; ++g) store_state<TK>(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
+    }
+    if (TK) wave_ticket_merge(p, b, h, tq, n_k, lane);
 }
 
 // Variant for G >= 4 query heads per kv head.  The per-(key, head) lane reductions of the
@@ -343,10 +482,11 @@ constexpr float kDecRaise = 8.0f;
 // G is the head count the kernel is laid out for (4 or 8); the launch may have fewer query heads per
 // kv head (p.G = 3, 5, 6, 7: e.g. 40 query / 8 kv heads): the surplus columns are zero queries whose
 // results are not stored.
-template <int G, bool ALIGNED, int kDepth, bool WGS>
+template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     static_assert(G == 4 || G == 8, "query heads per kv head");
     __shared__ __attribute__((aligned(16))) float xch_all[kDecWaves][16 * G + 16];
+    // workgroup items: the waves' states (its first word later carries the arrival number of the in-launch combine)
     __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -560,13 +700,16 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         }
 
     if (WGS) {
-        wg_merge_store<G>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
+        if (TK) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
         return;
     }
-    if (r4 != 0) return;
+    if (r4 == 0) {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-        if (g < p.G) store_state(p, b, h * p.G + g, split, tq, c, m[g], l[g], acc[g]);
+        for (int g = 0; g < G; ++g)
+            if (g < p.G) store_state<TK>(p, b, h * p.G + g, split, tq, c, m[g], l[g], acc[g]);
+    }
+    if (TK) wave_ticket_merge(p, b, h, tq, n_k, lane);
 }
 
 // Combine the per-chunk partial states of one (sequence, query head): 32 threads x 4 dims.
@@ -649,6 +792,11 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
 // batches, more loads in flight for small batches) at the price of more partials.
 // G >= 4 runs the MFMA-score kernel (about 200 registers: one 4-wave workgroup per SIMD set and
 // CU at a time), which measured fastest with one workgroup per CU; the VALU kernel wants two.
+// Split launches lay the workspace out as [arrival counters: kTicketRegion bytes][partial states].
+// The counter block has a fixed place and size so that memory the library owns (the built-in scratch)
+// never holds anything else there: it starts at zero and every launch leaves it at zero.
+constexpr int64_t kTicketRegion = 64 << 10;
+
 struct DecodePlan {
     int chunk;        // keys per work item
     int nsplit;       // work items per (sequence, kv head)
@@ -714,7 +862,7 @@ extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int 
     if (B <= 0 || H_q <= 0 || H_kv <= 0 || D != kHeadDim || max_seqlen_k < 0) return 0;
     const int ns = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv).nsplit;
     if (ns == 1) return 16;
-    return (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
+    return kTicketRegion + (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
 }
 
 namespace nv {
@@ -723,7 +871,7 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
                          const int32_t* block_tables, int B, int max_blocks, int max_seqlen_k, int H_q,
                          int H_kv, int D, int64_t num_blocks, int block_size, float scale,
                          int64_t q_stride_t, int64_t o_stride_t, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
+                         int64_t workspace_bytes, bool library_workspace, void* stream) {
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
                    num_blocks > 0 && block_size > 0,
                NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
@@ -753,7 +901,8 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     p.cu_q = cu_seqlens_q;
     p.cu_k = cu_seqlens_k;
     p.block_tables = block_tables;
-    p.part = (float*)workspace;
+    p.part = nullptr;
+    p.tickets = nullptr;
     p.B = B;
     p.max_blocks = max_blocks;
     p.H_kv = H_kv;
@@ -766,34 +915,63 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     p.q_stride_vec = q_stride_t / 8;
     p.o_stride_vec = o_stride_t / 8;
     p.scale_log2 = scale * 1.4426950408889634f;
+    hipStream_t st = (hipStream_t)stream;
+    bool single = false;
     if (p.nsplit > 1) {
-        const int64_t need = (int64_t)B * H_q * p.nsplit * kPartStride * (int64_t)sizeof(float);
+        const int64_t need = kTicketRegion + (int64_t)B * H_q * p.nsplit * kPartStride * (int64_t)sizeof(float);
         NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,
                    "nv_attn_decode_paged: workspace %lld bytes < required %lld",
                    (long long)workspace_bytes, (long long)need);
+        p.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + kTicketRegion);
+        // In-launch combine (the item that stores a pair's last partial state merges them): only on request
+        // (nv_tuning.decode_single_launch = 1).  Measured against the second launch on gfx950 it wins 4 % at
+        // 1 sequence x 32 k keys x 8 kv heads and loses 7 - 40 % where a launch has few (sequence, kv head)
+        // pairs or wave-sized items (the combining item's acquire and its serial walk over the partial
+        // states end the launch later than a 16-block merge kernel does).  A caller's workspace may hold
+        // anything, so its counters are zeroed on the stream ahead of the launch.
+        const int64_t ticket_bytes = ((int64_t)B * H_kv * (int64_t)sizeof(int) + 15) / 16 * 16;
+        single = tuning().decode_single_launch == 1 && ticket_bytes <= kTicketRegion;
+        if (single) {
+            p.tickets = static_cast<int*>(workspace);
+            if (!library_workspace) {
+                const hipError_t e = hipMemsetAsync(workspace, 0, (size_t)ticket_bytes, st);
+                NV_REQUIRE(e == hipSuccess, NV_ERR_LAUNCH, "nv_attn_decode_paged: hipMemsetAsync failed: %s",
+                           hipGetErrorString(e));
+            }
+        }
     }
     const int64_t items = (int64_t)B * p.nsplit * H_kv;
     const bool wgs = plan.wgs, lean = plan.lean, use_mfma = plan.mfma, mfma_deep = plan.mfma_deep;
     NV_REQUIRE(items < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
     const unsigned grid = wgs ? (unsigned)items : (unsigned)((items + kDecWaves - 1) / kDecWaves);
-    hipStream_t st = (hipStream_t)stream;
     const bool aligned = block_size % 16 == 0 && p.chunk % 64 == 0;
-#define NV_DEC_LAUNCH2(GG, AL)                                                                      \
+    // the in-launch combine lives in instantiations of its own (TK): the default kernels carry none of it
+#define NV_DEC_LAUNCH3(GG, AL, TK)                                                                  \
     do {                                                                                            \
-        if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);       \
-        else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 0, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
-        else hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
+        if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, true, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);       \
+        else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 0, false, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_kernel<GG, AL, 1, false, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
+    } while (0)
+#define NV_DEC_LAUNCH2(GG, AL)                   \
+    do {                                         \
+        if (single) NV_DEC_LAUNCH3(GG, AL, true); \
+        else NV_DEC_LAUNCH3(GG, AL, false);      \
     } while (0)
 #define NV_DEC_LAUNCH(GG)                    \
     do {                                     \
         if (aligned) NV_DEC_LAUNCH2(GG, true); \
         else NV_DEC_LAUNCH2(GG, false);      \
     } while (0)
-#define NV_DEC_LAUNCH_M2(GG, AL)                                                                    \
+#define NV_DEC_LAUNCH_M3(GG, AL, TK)                                                                \
     do {                                                                                            \
-        if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \
-        else if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
-        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 0, false>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);               \
+        if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, true, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \
+        else if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 1, false, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, AL, 0, false, TK>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);               \
+    } while (0)
+#define NV_DEC_LAUNCH_M2(GG, AL)                   \
+    do {                                           \
+        if (single) NV_DEC_LAUNCH_M3(GG, AL, true); \
+        else NV_DEC_LAUNCH_M3(GG, AL, false);      \
     } while (0)
 #define NV_DEC_LAUNCH_M(GG)                      \
     do {                                         \
@@ -815,13 +993,15 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
             break;
         default: NV_DEC_LAUNCH_M(8); break;
     }
+#undef NV_DEC_LAUNCH3
 #undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH
+#undef NV_DEC_LAUNCH_M3
 #undef NV_DEC_LAUNCH_M2
 #undef NV_DEC_LAUNCH_M
     int rc = check_launch("nv_attn_decode_paged");
     if (rc != NV_OK) return rc;
-    if (p.nsplit > 1) {
+    if (p.nsplit > 1 && !single) {
         if (p.nsplit > 16) {
             hipLaunchKernelGGL(attn_decode_merge_kernel<8>, dim3((unsigned)((int64_t)B * H_q)), dim3(256), 0, st, p, H_q);
         } else {
@@ -869,7 +1049,7 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
                                     void* stream) {
     return nv::decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
                              max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t,
-                             workspace, workspace_bytes, stream);
+                             workspace, workspace_bytes, false, stream);
 }
 
 extern "C" int64_t nv_attn_decode_static_scratch_bytes(void) {
@@ -893,9 +1073,10 @@ extern "C" int nv_attn_decode_paged_static(const void* q, const void* k_cache, c
     void* ptr = nullptr;
     const int rc = static_scratch_ptr(&ptr);
     if (rc != NV_OK) return rc;
-    // Nothing in the scratch has to start at zero: every partial state the merge reads is written by
-    // this call's attention kernel first.
+    // The scratch's first kTicketRegion bytes only ever hold the arrival counters of the in-launch combine:
+    // zero when the code object is loaded, and put back to zero by every launch that used them.  Every
+    // partial state a combine reads is written by this call's attention kernel first.
     return decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
                          max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t, ptr,
-                         kStaticScratchBytes, stream);
+                         kStaticScratchBytes, true, stream);
 }

@@ -414,10 +414,13 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     const int tiles = (max_seqlen_k + kBN - 1) / kBN;
     const nv_tuning tn = tuning();
     // The hand-scheduled kernel runs one workgroup per CU and never splits the key range: it takes the
-    // launches that fill the chip with 64-row waves (nv_tuning.prefill_kernel forces either kernel).
+    // launches that fill the chip with 64-row waves AND have long key ranges (nv_tuning.prefill_kernel
+    // forces either kernel).  Its fixed cost per workgroup is about 12 us against 8 us here, its cost per
+    // key tile lower: measured with 4096 workgroups it is 36 % slower at 1 tile per workgroup, 15 % at 4,
+    // equal at 8 and 9 - 13 % faster from 16 tiles on.
     prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 64);
     const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
-    sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : big_wgs >= 256;
+    sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : (big_wgs >= 256 && tiles >= 16);
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
     sh.pair_items = false;
     if (sh.hand_scheduled) {

@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     tn.decode_chunk = 128;
     tn.decode_work_item = 0;
     if (p_nv_set_tuning(&tn) != NV_OK) return 11;
-    if (p_nv_attn_decode_workspace_bytes(256, 16, 8, 128, 768) != 256LL * 16 * 6 * 132 * 4) return 12;
+    if (p_nv_attn_decode_workspace_bytes(256, 16, 8, 128, 768) != 65536 + 256LL * 16 * 6 * 132 * 4) return 12;   /* arrival counters + partial states */
     tn.decode_chunk = 100;                                  /* not a multiple of 64: refused, setting kept */
     if (p_nv_set_tuning(&tn) == NV_OK) return 13;
     if (p_nv_set_tuning(0) != NV_OK) return 14;

@@ -326,19 +326,32 @@ def test_decode_monotone_scores(hip, H_q, H_kv, direction):
     _attn_check(_run_attention(ops, pd, "decode"), ref, f"decode-{direction}")
 
 
+@pytest.mark.parametrize("single", [0, 1])
 @pytest.mark.parametrize("form", ["0", "1"])
 @pytest.mark.parametrize("H_q,H_kv,bs", [(16, 8, 256), (32, 8, 256), (8, 1, 256), (4, 4, 48)])
-def test_decode_both_work_item_forms(hip, tuning, form, H_q, H_kv, bs):
+def test_decode_both_work_item_forms(hip, tuning, form, single, H_q, H_kv, bs):
     """Work item = wave (0) or workgroup whose four waves split the chunk and merge in LDS (1), each
-    forced, with and without a global split (long and short contexts, empty quarters, 48-token blocks)."""
+    forced, with and without a global split (long and short contexts, empty quarters, 48-token blocks);
+    the partial states of split sequences combined by a second launch (single = 0) or inside the launch
+    by the work item that arrives last at the pair's counter (single = 1).  The in-launch form runs three
+    times in a row on one workspace: every launch has to leave the counters at zero, and the results must
+    be bit-identical from launch to launch and to the two-launch form's (same partial states, and both
+    combines must agree to fp32 rounding; the comparison is against the oracle at the usual tolerance)."""
     _, ops = hip
     n_ks = [1, 17, 63, 64, 65, 255, 700, 3000, 5000]
     nb = sum((n + bs - 1) // bs for n in n_ks) + 2
     p = make_paged_problem(H_q + bs, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb)
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
                                             p["block_tables"], p["scale"])
-    tuning(decode_work_item=int(form))
-    _attn_check(_run_attention(ops, to_dev(p), "decode"), ref, f"decode-form{form}")
+    pd = to_dev(p)
+    tuning(decode_work_item=int(form), decode_single_launch=single, decode_chunk=256)
+    outs = [_run_attention(ops, pd, "decode") for _ in range(3 if single else 1)]
+    for o in outs:
+        _attn_check(o, ref, f"decode-form{form}-single{single}")
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "in-launch combine differs between consecutive launches"
+    tuning(decode_work_item=int(form), decode_single_launch=single)
+    _attn_check(_run_attention(ops, pd, "decode"), ref, f"decode-form{form}-single{single}-auto-chunk")
 
 
 @pytest.mark.parametrize("H_q,H_kv", [(12, 4), (40, 8), (24, 4), (28, 4)])
@@ -476,6 +489,30 @@ def test_prefill_hand_scheduled_kernel_rescale_and_nan_tails(hip, tuning):
     wide[:, :H_q * D] = pd["q"].view(T, -1)
     pd["q"] = wide[:, :H_q * D].view(T, H_q, D)
     _attn_check(_run_attention(ops, pd, "prefill"), ref, "hand-bs64-strided")
+
+
+@pytest.mark.parametrize("n_qs,n_ks", [
+    ([1024] * 16, [1024] * 16),                                   # 4 query tiles per head: pairs (3, 0), (2, 1)
+    ([768] * 22, [768] * 22),                                     # 3 tiles: the middle one is a lone second item
+    ([960, 1000, 64, 70] * 4, [960, 1300, 64, 326] * 4),          # ragged and chunked sequences in one launch
+])
+def test_prefill_hand_scheduled_kernel_two_tiles_per_workgroup(hip, tuning, n_qs, n_ks):
+    """Launches with many workgroups give every workgroup two query tiles of one head (the last and the
+    first, the second last and the second, ...): the second tile's first key tiles and its Q fragments are
+    fetched while the first tile finishes.  A key with a much larger score late in the visible range of a
+    row of the FIRST query tile (processed second) drives the accumulator rescale through that path too."""
+    _, ops = hip
+    H_q, H_kv, bs = 16, 2, 256
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+    p = make_paged_problem(len(n_qs) + n_qs[0], n_qs, n_ks, H_q, H_kv, bs, nb)
+    shift = n_ks[0] - n_qs[0]
+    j = shift + 90                                                # visible to query rows >= 90 of sequence 0
+    blk = p["block_tables"][0, j // bs].item()
+    p["k_cache"][blk, j % bs] = (p["q"][100, 3] * 3).to(torch.bfloat16)[None, :].expand(H_kv, -1)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    tuning(prefill_kernel=1)
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-hand-pairs")
 
 
 def test_prefill_key_range_split_long_chunk(hip):

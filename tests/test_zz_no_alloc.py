@@ -1,7 +1,10 @@
-"""GPU: the allocation-free decode entry point (nv_attn_decode_paged_static, split-key partial states in
-a device array built into the library) against nv_attn_decode_paged with a caller workspace: the same
-kernels on the same plan, so the outputs must be bit-identical.  Two calls in a row, the second on a
-smaller input, so that stale partial states of the first call would show."""
+"""GPU: the allocation-free decode entry point (nv_attn_decode_paged_static, split-key partial states and
+arrival counters in a device array built into the library) against nv_attn_decode_paged with a caller
+workspace: the same kernels on the same plan, so the outputs must be bit-identical, with the partial
+states of split sequences combined by a second launch (the default) and inside the launch (where the
+library's counters must be zero before the first call and after every call).  Two calls in a row per
+form, the second on a smaller input, so that stale partial states or counters of the first call would
+show."""
 import pytest
 import torch
 
@@ -33,23 +36,28 @@ def _both(dll, p, H_q, H_kv, bs):
     return o_ws, o_st, need
 
 
-def test_static_scratch_entry_point_matches_workspace_entry_point():
+@pytest.mark.parametrize("single", [0, 1, -1])
+def test_static_scratch_entry_point_matches_workspace_entry_point(single):
     assert torch.cuda.is_available()
     from nanovllm_amd import _lib
     dll = _lib.lib()
     cap = dll.nv_attn_decode_static_scratch_bytes()
     assert cap == 32 << 20
     H_q, H_kv, bs = 32, 8, 256
-    # first call: long contexts, many key chunks per (sequence, kv head); second: fewer, shorter sequences
-    for seed, n_ks in ((1, [5000, 8192, 300, 4097]), (2, [2049, 700])):
-        nb = sum((n + bs - 1) // bs for n in n_ks) + 1
-        p = make_paged_problem(seed, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb, device=DEV)
-        o_ws, o_st, need = _both(dll, p, H_q, H_kv, bs)
-        assert 16 < need <= cap                                   # the split path (scratch in use)
-        assert torch.equal(o_ws.view(torch.int16), o_st.view(torch.int16))
-        ref = ref_attention.paged_attention_ref(p["q"].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(), p["cu_q"].cpu(),
-                                                p["cu_k"].cpu(), p["block_tables"].cpu(), p["scale"])
-        assert (o_st.float().cpu() - ref).abs().max().item() <= 2e-2
+    _lib.set_tuning(decode_single_launch=single)
+    try:
+        # first call: long contexts, many key chunks per (sequence, kv head); second: fewer, shorter sequences
+        for seed, n_ks in ((1, [5000, 8192, 300, 4097]), (2, [2049, 700])):
+            nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+            p = make_paged_problem(seed, [1] * len(n_ks), n_ks, H_q, H_kv, bs, nb, device=DEV)
+            o_ws, o_st, need = _both(dll, p, H_q, H_kv, bs)
+            assert 16 < need <= cap                                   # the split path (scratch in use)
+            assert torch.equal(o_ws.view(torch.int16), o_st.view(torch.int16))
+            ref = ref_attention.paged_attention_ref(p["q"].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(),
+                                                    p["cu_q"].cpu(), p["cu_k"].cpu(), p["block_tables"].cpu(), p["scale"])
+            assert (o_st.float().cpu() - ref).abs().max().item() <= 2e-2
+    finally:
+        _lib.set_tuning()
     # an unsplit launch needs no scratch and still runs
     p = make_paged_problem(3, [1] * 300, [70] * 300, 16, 8, bs, 301, device=DEV)
     o_ws, o_st, need = _both(dll, p, 16, 8, bs)
