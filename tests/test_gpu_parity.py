@@ -515,6 +515,20 @@ def test_prefill_hand_scheduled_kernel_two_tiles_per_workgroup(hip, tuning, n_qs
     _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-hand-pairs")
 
 
+def test_prefill_hand_scheduled_kernel_on_engine_step_shapes_with_guard_rows(hip):
+    """The launches of an engine prefill step (16 / 8 heads, 8 - 10 ragged sequences, chunk tails of a few
+    rows, q a strided slice of a fused qkv buffer, query offsets that do not start at 0), 100 launch pairs:
+    the hand-scheduled kernel must agree with the compiler-scheduled one and must not touch the canary
+    rows in front of and behind the output (a wave whose rows lie behind the end of its sequence stores
+    nothing)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import prefill_stress
+    launches, bad = prefill_stress.run(rounds=10, verbose=False)
+    assert launches == 100 and bad == 0
+
+
 def test_prefill_key_range_split_long_chunk(hip):
     """One long sequence prefilled in a chunk: too few workgroups for the chip, so the launch splits
     the key range over several workgroups and merges their states in a second launch."""

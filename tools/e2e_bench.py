@@ -120,7 +120,12 @@ if __name__ == "__main__":
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous decode loop (token values read every step)")
     ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode"])
     ap.add_argument("--ctx", type=int, default=32768)
+    ap.add_argument("--prefill-kernel", type=int, default=-1, choices=[-1, 0, 1],
+                    help="force the compiler-scheduled (0) or the hand-scheduled (1) prefill kernel; -1 = heuristic")
     a = ap.parse_args()
+    if a.prefill_kernel >= 0:
+        from nanovllm_amd import _lib
+        _lib.set_tuning(prefill_kernel=a.prefill_kernel)
     if a.scenario == "long_prompt":
         print(json.dumps(run_long_prompt_with_shared_prefix(a.model if a.model != "qwen3_0_6b" else "qwen3_8b")))
         sys.exit(0)

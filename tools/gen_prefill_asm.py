@@ -469,9 +469,12 @@ def read_descriptor(o: Out, item_sreg, into_next=False):
     """Item descriptor (8 dwords at s_desc + 32 item): nt, mask_from, rw0 + shift, rw0, rows."""
     o.e(f"s_lshl_b32 s{S_T0}, s{item_sreg}, 5")
     o.e(f"s_add_u32 s{S_T0}, s{S_T0}, s{S_DESC}")
-    o.e(f"v_mov_b32 v{T[0]}, s{S_T0}")
-    o.e(f"ds_read_b128 v[250:253], v{T[0]}")
-    o.e(f"ds_read_b32 v254, v{T[0]} offset:16")
+    # the address register must not be one of the destinations: the second read is issued while the first
+    # may already have returned (rarely, when the LDS queue holds the issue back), and would then take a
+    # descriptor word for its address
+    o.e(f"v_mov_b32 v{T[5]}, s{S_T0}")
+    o.e(f"ds_read_b128 v[250:253], v{T[5]}")
+    o.e(f"ds_read_b32 v254, v{T[5]} offset:16")
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_nop 1")
     if into_next:
