@@ -2,6 +2,7 @@
 `nano-vllm_amd/` to the package `nanovllm_amd`) imports from a clean directory without the root shim, ships
 the HIP library, and that library exports the C ABI."""
 import os
+import shutil
 import subprocess
 import sys
 import zipfile
@@ -13,6 +14,8 @@ def test_wheel_imports_without_the_root_shim(tmp_path):
     out = tmp_path / "whl"
     r = subprocess.run([sys.executable, "-m", "pip", "wheel", ROOT, "--no-deps", "--no-build-isolation", "-q",
                         "-w", str(out)], capture_output=True, text=True, cwd=str(tmp_path))
+    for leftover in ("build/lib", "build/bdist.linux-x86_64", "nanovllm_amd.egg-info"):   # the in-tree build's litter
+        shutil.rmtree(os.path.join(ROOT, leftover), ignore_errors=True)
     assert r.returncode == 0, r.stderr[-2000:]
     wheels = [f for f in os.listdir(out) if f.endswith(".whl")]
     assert len(wheels) == 1 and wheels[0].startswith("nanovllm_amd-")
