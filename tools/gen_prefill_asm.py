@@ -7,22 +7,31 @@ The output is ONE inline-asm body (a C++ raw string) used by csrc/attn_prefill_a
 query rows (two 32-row blocks qb) of one query head and the whole 512-entry register file:
 
   AGPR  a[0:127]    O^T accumulators   O(qb, d, i)   = 64 qb + 16 d + i        (d = 32-dim block)
-        a[128:191]  Q fragments        Q(qb, s, w)   = 128 + 32 qb + 4 s + w   (s = 16-dim k-step)
+        a[128:191]  Q fragments        Q(qb, s, w)   = 128 + 32 qb + 4 s + w   (s = 16-dim k-step), PRE-SCALED
         a[192:255]  K fragments        K(kb, s, w)   = 192 + 32 kb + 4 s + w   (kb = 32-key block)
   VGPR  v[0:127]    S^T, two tiles     S(buf, kb, qb, i) = 64 buf + 32 kb + 16 qb + i
-        v[128:191]  V^T fragments      V(d, ks, w)   = 128 + 16 d + 4 ks + w   (ks = 16-key k-step)
+        v[128:159]  V^T fragments      V(d, ks, w)   = 128 + 16 (ks & 1) + 4 d + w   (two of the four k-steps)
+        v[160:191]  -m blocks          NMB(qb, i)    = 160 + 16 qb + i   (minus the running maximum, 16 copies)
         v[192:223]  P^T fragments      P(ks, qb, w)  = 192 + 8 ks + 4 qb + w
         v[224:255]  softmax state, lane-constant addresses, temporaries
 
+Softmax without a multiply-add per score: the Q fragments are multiplied by scale * log2(e) once per item
+(bf16), and every S^T accumulator chain STARTS from the block that holds minus the running maximum of its
+query rows (the MFMA's C operand), so an accumulator is already  scale * log2(e) * q.k - m  and the
+probability is exp2 of it.  The running maximum is raised (rarely: when a tile maximum exceeds it by more than
+2^8) in a side path that also shifts the tile's accumulators and the -m blocks.
+
 Tile j (64 keys) is processed by a two-phase software pipeline; iteration j of the loop is
-  phase 1: 32 MFMAs  S(j) = K(j) Q^T     beside  exp / row sums / bf16 packing of the second half of S(j-1),
-                                                 transposed LDS reads of V(j-1), LDS-DMA of K(j+2), V(j)
-  phase 2: 32 MFMAs  O += V(j-1)^T P(j-1) beside  row maxima of S(j), exp of its first half, LDS reads of
-                                                 K(j+1)
-with at most ~5 single-issue instructions behind each MFMA (one wave per SIMD hides about that many).
+  phase 1: 32 MFMAs  S(j) = K(j) Q^T - m   beside  the rest of exp / row sums / bf16 packing of S(j-1),
+                                                   transposed LDS reads of k-steps 0, 1 of V(j-1), LDS-DMA of
+                                                   K(j+2), V(j)
+  phase 2: 32 MFMAs  O += V(j-1)^T P(j-1)  beside  row maxima of S(j), the first part of its exp stream, LDS
+                                                   reads of k-steps 2, 3 of V(j-1) (into the registers of
+                                                   k-steps 0, 1 once those MFMAs have issued; counted waits)
+                                                   and of K(j+1)
+with 4 - 5 single-issue instructions behind each MFMA (one wave per SIMD hides about five).
 One workgroup barrier per tile; K/V tiles arrive by LDS-DMA one iteration before they are read.
-Masked tiles (causal diagonal, end of the sequence) start their S accumulators from a 0 / -inf tile
-instead of 0; the accumulator rescale (running maximum raised by more than 2^8) is a rare side path.
+Masked tiles (causal diagonal, end of the sequence) start their S accumulators from a -m / -inf tile.
 """
 from __future__ import annotations
 
@@ -34,14 +43,13 @@ OUT = os.path.join(ROOT, "nano-vllm_amd", "csrc", "attn_prefill_loop.inc")
 
 # ---- register map ------------------------------------------------------------------------------
 def S(buf, kb, qb, i=0): return 64 * buf + 32 * kb + 16 * qb + i
-def Vf(d, ks, w=0): return 128 + 16 * d + 4 * ks + w
+def Vf(d, ks, w=0): return 128 + 16 * (ks & 1) + 4 * d + w
+def NMB(qb, i=0): return 160 + 16 * qb + i
 def P(ks, qb, w=0): return 192 + 8 * ks + 4 * qb + w
 def O(qb, d, i=0): return 64 * qb + 16 * d + i
 def Q(qb, s, w=0): return 128 + 32 * qb + 4 * s + w
 def K(kb, s, w=0): return 192 + 32 * kb + 4 * s + w
 
-NM = [224, 228]     # MINUS the running maximum per 32-row block (log2 domain, scale folded in), held twice
-                    # (v[NM:NM+1]) so that the packed fma reads it as a plain 64-bit operand
 L = [226, 246]      # this lane's share of the running denominator: two partial sums per block, v[L:L+1]
 TM = [230, 231]     # tile maximum (raw scores)
 AL = TM             # pending accumulator rescale factor: written by the side path after it has consumed the maximum
@@ -63,7 +71,6 @@ S_QSEQ, S_OSEQ = 72, 74        # 64-bit: row 0 of this wave's query head in q / 
 S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
 S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
 S_SAVE = 82                    # s[82:83] saved exec
-S_ONES = 85                    # two bf16 ones
 S_LAST = 84                    # index of the next item while an epilogue prefetches for it
 
 # LDS layout (bytes)
@@ -98,9 +105,10 @@ def rng(kind, base, n):
 
 
 # ---- instruction streams -------------------------------------------------------------------------
-def qk_mfmas(buf, masked_label_prefix):
-    """32 MFMAs S^T[kb][qb] = sum_s K[kb][s] Q[qb][s]; chain starts take C = 0, or C = the preset mask tile
-    through an out-of-line copy when the tile is masked.  Returns (list of (text, out_of_line_text))."""
+def qk_mfmas(buf, masked_label_prefix, cinit=True):
+    """32 MFMAs S^T[kb][qb] = sum_s K[kb][s] Q[qb][s] (+ C); a chain starts from the -m block of its query
+    rows (cinit) or from 0 (first tile of an item), or, when the tile is masked, from the preset mask tile
+    through an out-of-line copy.  Returns a list of (kind, d, a, b, label, c)."""
     ms = []
     n = 0
     for kb in range(2):
@@ -110,10 +118,11 @@ def qk_mfmas(buf, masked_label_prefix):
                 a = rng("a", K(kb, s), 4)
                 b = rng("a", Q(qb, s), 4)
                 if s == 0:
-                    ms.append(("start", d, a, b, f"{masked_label_prefix}_{n}"))
+                    c = rng("v", NMB(qb), 16) if cinit else "0"
+                    ms.append(("start", d, a, b, f"{masked_label_prefix}_{n}", c))
                     n += 1
                 else:
-                    ms.append(("acc", d, a, b, None))
+                    ms.append(("acc", d, a, b, None, None))
     return ms
 
 
@@ -127,10 +136,11 @@ def pv_mfmas():
     return ms
 
 
-def v_reads(slot):
-    """32 transposed reads of a V tile into the V^T fragment registers, k-step major."""
+def v_reads(slot, ks_list):
+    """Transposed reads of the given k-steps of a V tile into the V^T fragment registers (k-steps 0 / 2 and
+    1 / 3 share registers)."""
     out = []
-    for ks in range(4):
+    for ks in ks_list:
         for d in range(4):
             off = slot * SLOT + V_OFF + 4096 * ks + 512 * d
             out.append(f"ds_read_b64_tr_b16 {rng('v', Vf(d, ks, 0), 2)}, v{VB[0]} offset:{off}")
@@ -147,54 +157,51 @@ def k_reads(slot):
     return out
 
 
-def exp_stream(buf, kb, with_cvt=True):
-    """exp2(S * c - m) in place, row sums, packing to bf16 pairs for the S registers of key block kb.
-    Per two values: one packed fma, two exponentials, one packed add into the two partial row sums, one
-    packing conversion.  The stream is skewed by one pair so that the two exponentials of a pair are never
-    neighbours and nothing reads an exponential in the instruction after it."""
+N_P2 = int(os.environ.get("PF_NP2", "11"))   # value pairs of key block 0 whose exp stream runs in phase 2
+
+
+def exp_pairs(buf, kb):
+    """Per value pair of the S registers of key block kb: (exp a, exp b, add a, add b, cvt).  The accumulators
+    already hold scale * log2(e) * q.k - m."""
     pairs = []
     for qb in range(2):
         for i in range(0, 16, 2):
             ra, rb = S(buf, kb, qb, i), S(buf, kb, qb, i + 1)
-            # operands without half selection on the 64-bit register sources: a packed fma that picked the
-            # upper half of a register pair for its lower result gave wrong values in single 16-lane groups
-            # now and then (timing dependent); the scalar pair is read as one replicated dword
-            fma = f"v_pk_fma_f32 v[{ra}:{rb}], v[{ra}:{rb}], s[{S_C}:{S_C + 1}], v[{NM[qb]}:{NM[qb] + 1}] op_sel_hi:[1,0,1]"
-            add = f"v_pk_add_f32 v[{L[qb]}:{L[qb] + 1}], v[{L[qb]}:{L[qb] + 1}], v[{ra}:{rb}]"
-            if not PK_FMA:
-                fma = [f"v_fma_f32 v{ra}, v{ra}, s{S_C}, v{NM[qb]}", f"v_fma_f32 v{rb}, v{rb}, s{S_C}, v{NM[qb]}"]
-            if not PK_ADD:
-                add = [f"v_add_f32 v{L[qb]}, v{L[qb]}, v{ra}", f"v_add_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{rb}"]
-            cvt = None
-            if with_cvt:
-                ks = 2 * kb + (i >> 3)
-                w = (i & 7) >> 1
-                cvt = ("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}")
-                if DOT2:
-                    lr = L[qb] + ((i >> 1) & 1)
-                    add = ("cvt", f"v_dot2_f32_bf16 v{lr}, v{P(ks, qb, w)}, s{S_ONES}, v{lr}")
-            pairs.append((fma, f"v_exp_f32 v{ra}, v{ra}", f"v_exp_f32 v{rb}, v{rb}", add, cvt))
-    if DOT2:
-        pairs = [(f, ea, eb, c, a) for (f, ea, eb, a, c) in pairs]      # conversion first, then the dot
-    out = [pairs[0][0]]
-    for n, (fma, ea, eb, add, cvt) in enumerate(pairs):
+            ks = 2 * kb + (i >> 3)
+            w = (i & 7) >> 1
+            pairs.append((f"v_exp_f32 v{ra}, v{ra}", f"v_exp_f32 v{rb}, v{rb}",
+                          f"v_add_f32 v{L[qb]}, v{L[qb]}, v{ra}", f"v_add_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{rb}",
+                          ("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}")))
+    return pairs
+
+
+def flatten_pairs(pairs):
+    """Skewed by one pair: the two exponentials of a pair are not neighbours and nothing reads an
+    exponential in the instruction after it."""
+    out = []
+    for n, (ea, eb, aa, ab, cv) in enumerate(pairs):
         out.append(ea)
-        if n + 1 < len(pairs):
-            out.append(pairs[n + 1][0])
-        elif n > 0:
-            out.append(pairs[n - 1][3])
+        if n > 0:
+            out.append(pairs[n - 1][2])
         out.append(eb)
-        if n > 0 and n + 1 < len(pairs):
+        if n > 0:
             out.append(pairs[n - 1][3])
-        if n > 0 and pairs[n - 1][4]:
             out.append(pairs[n - 1][4])
-    out.append(pairs[-1][3])
-    if pairs[-1][4]:
-        out.append(pairs[-1][4])
-    flat = []
-    for x in out:
-        flat += x if isinstance(x, list) else [x]
-    return flat
+    if pairs:
+        out += [pairs[-1][2], pairs[-1][3], pairs[-1][4]]
+    return out
+
+
+def exps_p2(buf):
+    return flatten_pairs(exp_pairs(buf, 0)[:N_P2])
+
+
+def exps_p1(buf):
+    return flatten_pairs(exp_pairs(buf, 0)[N_P2:] + exp_pairs(buf, 1))
+
+
+def plain(xs):
+    return [x[1] if isinstance(x, tuple) else x for x in xs]
 
 
 def max_stream(buf):
@@ -220,13 +227,8 @@ def max_stream(buf):
 
 STATS: dict = {}
 # placement knobs (experiments): MFMAs of phase 2 that carry the maxima; spacing of the V reads in phase 1
-# Measured on gfx950 inside this loop: v_pk_fma_f32 / v_pk_add_f32 cost more issue time than the two plain
-# instructions they replace (the 4 x 8192 case ran 12 % slower with both), so they stay off.
-PK_FMA = os.environ.get("PF_PKFMA", "0") == "1"
-PK_ADD = os.environ.get("PF_PKADD", "0") == "1"
-DOT2 = os.environ.get("PF_DOT2", "0") == "1"      # row sums from the packed bf16 pair: one dot instruction per pair
-N_HEAD = int(os.environ.get("PF_NHEAD", "12"))
-VR_MOD = tuple(int(x) for x in os.environ.get("PF_VRMOD", "2,0").split(","))
+# (v_pk_fma_f32 / v_pk_add_f32 / v_dot2_f32_bf16 in the exp stream measured slower than the plain instructions
+# they replace; see the experiments notes of the profiles directory.)
 # timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,lgkm
 ABLATE = set(filter(None, os.environ.get("PF_ABLATE", "").split(",")))
 
@@ -296,21 +298,22 @@ def emit_mfma(o: Out, m):
     if isinstance(m, str):
         o.e(m)
         return
-    kind, d, a, b, lab = m
+    kind, d, a, b, lab, c = m
     if kind == "acc":
         o.e(f"{MFMA} {d}, {a}, {b}, {d}")
         return
-    # chain start: C = 0, or C = the mask tile already sitting in the accumulator registers
+    # chain start: C = the -m block (or 0), or C = the mask tile already sitting in the accumulator registers
     o.e(f"s_cmp_lg_u32 s{S_MASKED}, 0")
     o.e(f"s_cbranch_scc1 {lab}")
-    o.e(f"{MFMA} {d}, {a}, {b}, 0")
+    o.e(f"{MFMA} {d}, {a}, {b}, {c}")
     o.label(f"{lab}_ret")
     _ool.append([f"{lab}:", f"  {MFMA} {d}, {a}, {b}, {d}", f"  s_branch {lab}_ret"])
 
 
 # ---- building blocks -------------------------------------------------------------------------------
-def mask_setup(o: Out, buf, tag):
-    """s_masked = (j >= mask_from); a masked tile presets S(buf) with 0 (visible) / -inf (hidden)."""
+def mask_setup(o: Out, buf, tag, first=False):
+    """s_masked = (j >= mask_from); a masked tile presets S(buf) with -m (visible; 0 for the first tile of an
+    item, whose chains start from 0) / -inf (hidden)."""
     o.e(f"s_cmp_ge_u32 s{S_J}, s{S_MASKFROM}")
     o.e(f"s_cselect_b32 s{S_MASKED}, 1, 0")
     o.e(f"s_cbranch_scc1 .Lpf_mask_{tag}")
@@ -320,6 +323,7 @@ def mask_setup(o: Out, buf, tag):
         blk.append(f"  v_subrev_u32 v{T[qb]}, s{S_T0}, v{QPOS[qb]}")
     blk.append("  s_nop 1")
     for qb in range(2):
+        vis = "0" if first else f"v{NMB(qb)}"
         for kb in range(2):
             for i0 in range(0, 16, 4):
                 for k in range(4):
@@ -327,7 +331,7 @@ def mask_setup(o: Out, buf, tag):
                     key = kb * 32 + (i & 3) + 8 * (i >> 2)
                     blk.append(f"  v_cmp_ge_i32 s[{S_CMP + 2 * k}:{S_CMP + 2 * k + 1}], v{T[qb]}, {key}")
                 for k in range(4):
-                    blk.append(f"  v_cndmask_b32 v{S(buf, kb, qb, i0 + k)}, v{NINF}, 0, "
+                    blk.append(f"  v_cndmask_b32 v{S(buf, kb, qb, i0 + k)}, v{NINF}, {vis}, "
                                f"s[{S_CMP + 2 * k}:{S_CMP + 2 * k + 1}]")
     blk.append("  s_nop 3")
     blk.append(f"  s_branch .Lpf_mask_{tag}_ret")
@@ -369,29 +373,52 @@ def table_lookup(o_list, tile_off_bytes_K, tile_off_bytes_V):
     o_list.append(f"ds_read_b64 v[254:255], v{T[0]} offset:{tile_off_bytes_V}")
 
 
-def slow_max(o: Out, tag):
-    """Decision of the deferred rescale: any row whose tile maximum exceeds the running one by more than
-    2^8 sends the wave through the side path that raises the maxima and records the factors."""
-    o.e(f"v_fma_f32 v{T[0]}, v{TM[0]}, s{S_C}, v{NM[0]}")
-    o.e(f"v_fma_f32 v{T[1]}, v{TM[1]}, s{S_C}, v{NM[1]}")
-    o.e(f"v_max_f32 v{T[0]}, v{T[0]}, v{T[1]}")
+def slow_max(o: Out, buf, tag):
+    """Decision of the deferred rescale.  The tile maxima are relative to the running maxima already: any row
+    above 2^8 sends the wave through the side path, which raises the maxima of all rows by max(tile maximum, 0):
+    shifts the tile's accumulators and the -m blocks, records the factors and rescales the row sums."""
+    o.e(f"v_max_f32 v{T[0]}, v{TM[0]}, v{TM[1]}")
     o.e(f"v_cmp_lt_f32 vcc, {EIGHT}, v{T[0]}")
     o.e(f"s_cbranch_vccnz .Lpf_slow_{tag}")
     o.label(f".Lpf_slow_{tag}_ret")
     blk = [f".Lpf_slow_{tag}:"]
     for qb in range(2):
-        blk += [f"  v_mul_f32 v{T[0]}, s{S_C}, v{TM[qb]}",
-                f"  v_sub_f32 v{T[0]}, 0, v{T[0]}",
-                f"  v_min_f32 v{T[0]}, v{NM[qb]}, v{T[0]}",          # minus the new maximum
-                f"  v_sub_f32 v{T[1]}, v{T[0]}, v{NM[qb]}",          # old maximum - new maximum <= 0
-                f"  v_exp_f32 v{AL[qb]}, v{T[1]}",
-                f"  v_mov_b32 v{NM[qb]}, v{T[0]}",
-                f"  v_mov_b32 v{NM[qb] + 1}, v{T[0]}",
-                "  s_nop 0",
-                f"  v_mul_f32 v{L[qb]}, v{L[qb]}, v{AL[qb]}",
+        blk.append(f"  v_max_f32 v{T[qb]}, 0, v{TM[qb]}")
+    for qb in range(2):
+        blk.append(f"  v_exp_f32 v{AL[qb]}, -v{T[qb]}")
+    for qb in range(2):
+        for kb in range(2):
+            for i in range(16):
+                r = S(buf, kb, qb, i)
+                blk.append(f"  v_sub_f32 v{r}, v{r}, v{T[qb]}")
+        for i in range(16):
+            blk.append(f"  v_sub_f32 v{NMB(qb, i)}, v{NMB(qb, i)}, v{T[qb]}")
+    for qb in range(2):
+        blk += [f"  v_mul_f32 v{L[qb]}, v{L[qb]}, v{AL[qb]}",
                 f"  v_mul_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{AL[qb]}"]
-    blk += [f"  s_mov_b32 s{S_RESC}, 1", f"  s_branch .Lpf_slow_{tag}_ret"]
+    blk += [f"  s_mov_b32 s{S_RESC}, 1", "  s_nop 3", f"  s_branch .Lpf_slow_{tag}_ret"]
     _ool.append(blk)
+
+
+def first_tile_max(o: Out):
+    """First tile of an item (its chains started from 0): the running maxima become the tile maxima (not
+    below -1e30, which keeps rows without any visible key free of inf - inf)."""
+    for qb in range(2):
+        o.e(f"v_max_f32 v{T[qb]}, {NEG_BIG}, v{TM[qb]}")
+    for qb in range(2):
+        for kb in range(2):
+            for i in range(16):
+                r = S(0, kb, qb, i)
+                o.e(f"v_sub_f32 v{r}, v{r}, v{T[qb]}")
+        o.e(f"v_sub_f32 v{NMB(qb, 0)}, 0, v{T[qb]}")
+        for i in range(1, 16):
+            o.e(f"v_mov_b32 v{NMB(qb, i)}, v{NMB(qb, 0)}")
+
+
+def lds_ops_after(lines, marker):
+    """Number of LDS instructions in `lines` behind the last line that contains `marker`."""
+    last = max(i for i, ln in enumerate(lines) if marker in ln)
+    return sum(1 for ln in lines[last + 1:] if ln.strip().startswith("ds_"))
 
 
 def rescale_check(o: Out, tag):
@@ -507,7 +534,6 @@ def gen_setup(o: Out):
             o.e(f"s_mov_b32 s{r}, %{i}")
     o.e(f"s_mov_b32 s{S_ITEM}, 0")
     o.e(f"s_mov_b32 s{S_RESC}, 0")
-    o.e(f"s_mov_b32 s{S_ONES}, 0x3f803f80")
     o.e(f"v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0")
     o.e(f"v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}")
     o.e(f"v_lshlrev_b32 v{PADDR}, 2, v{T[0]}")
@@ -515,14 +541,36 @@ def gen_setup(o: Out):
     for pi, r in enumerate([KB[0], KB[1], VB[0], VB[1]]):
         o.e(f"ds_read_b32 v{r}, v{PADDR} offset:{PARAM_OFF + pi * 256}")
     o.e(f"v_mov_b32 v{NINF}, 0xff800000")
-    o.c("first item: its descriptor, its Q fragments, tiles 0 and 1")
+    o.c("first item: its descriptor; its Q fragments travel to the K fragment registers (scaled into place later)")
     read_descriptor(o, S_ITEM)
     lane_consts(o)
-    q_fetch(o, S_RW0, Q(0, 0))
+    q_fetch(o, S_RW0, K(0, 0))
+
+
+def q_prescale(o: Out):
+    """Q fragments (bf16 pairs) from the K fragment registers, times scale * log2(e), to their own registers."""
+    tmp = [T[0], T[1], T[2], T[3]]
+    for i0 in range(0, 64, 2):
+        for k in range(2):
+            o.e(f"v_accvgpr_read_b32 v{tmp[2 * k]}, a{K(0, 0) + i0 + k}")
+        o.e("s_nop 0")
+        for k in range(2):
+            o.e(f"v_lshlrev_b32 v{tmp[2 * k + 1]}, 16, v{tmp[2 * k]}")
+        for k in range(2):
+            o.e(f"v_and_b32 v{tmp[2 * k]}, 0xffff0000, v{tmp[2 * k]}")
+        for k in range(2):
+            o.e(f"v_mul_f32 v{tmp[2 * k + 1]}, s{S_C}, v{tmp[2 * k + 1]}")
+            o.e(f"v_mul_f32 v{tmp[2 * k]}, s{S_C}, v{tmp[2 * k]}")
+        for k in range(2):
+            o.e(f"v_cvt_pk_bf16_f32 v{tmp[2 * k]}, v{tmp[2 * k + 1]}, v{tmp[2 * k]}")
+        o.e("s_nop 0")
+        for k in range(2):
+            o.e(f"v_accvgpr_write_b32 a{Q(0, 0) + i0 + k}, v{tmp[2 * k]}")
 
 
 def gen_item_prologue(o: Out):
-    """Start of an item.  On entry: descriptor scalars loaded, Q fragments of the item in flight or landed."""
+    """Start of an item.  On entry: descriptor scalars loaded, Q fragments of the item in flight to (or landed
+    in) the K fragment registers."""
     o.label(".Lpf_item")
     for i in range(4):
         o.e(f"ds_read_b32 v{DOFFK[i]}, v{PADDR} offset:{PARAM_OFF + (4 + i) * 256}")
@@ -531,8 +579,6 @@ def gen_item_prologue(o: Out):
     o.e(f"ds_read_b32 v{QPOS[1]}, v{PADDR} offset:{PARAM_OFF + 13 * 256}")
     o.e(f"s_mov_b32 s{S_J}, 0")
     for qb in range(2):
-        o.e(f"v_mov_b32 v{NM[qb]}, {POS_BIG}")
-        o.e(f"v_mov_b32 v{NM[qb] + 1}, {POS_BIG}")
         o.e(f"v_mov_b32 v{L[qb]}, 0")
         o.e(f"v_mov_b32 v{L[qb] + 1}, 0")
     for i in range(128):
@@ -546,18 +592,9 @@ def gen_item_prologue(o: Out):
     tile_fetch_const(o, 0, "K", 0, DOFFK, "pro_k0", False)
     tile_fetch_const(o, 0, "V", 0, DOFFV, "pro_v0", False)
     tile_fetch_const(o, 1, "K", 1, DOFFK, "pro_k1", False)
-    o.e("s_waitcnt vmcnt(0)")
-    o.e("s_branch .Lpf_fetched")
     o.label(".Lpf_prefetched")
-    o.c("the item before fetched tiles 0 / 1 of this item and loaded its Q fragments into the K registers")
     o.e("s_waitcnt vmcnt(0)")
-    for i0 in range(0, 64, 4):
-        for k in range(4):
-            o.e(f"v_accvgpr_read_b32 v{T[k]}, a{K(0, 0) + i0 + k}")
-        o.e("s_nop 0")
-        for k in range(4):
-            o.e(f"v_accvgpr_write_b32 a{Q(0, 0) + i0 + k}, v{T[k]}")
-    o.label(".Lpf_fetched")
+    q_prescale(o)
     o.e("s_barrier")
     o.e(f"s_cmp_eq_u32 s{S_NT}, 0")
     o.e("s_cbranch_scc1 .Lpf_fin")
@@ -566,23 +603,19 @@ def gen_item_prologue(o: Out):
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_barrier")
     tile_fetch_const(o, 2, "K", 0, DOFFK, "pro_k2", False)
-    mask_setup(o, 0, "pro")
-    for m in qk_mfmas(0, ".Lpf_mm_pro"):
+    mask_setup(o, 0, "pro", first=True)
+    for m in qk_mfmas(0, ".Lpf_mm_pro", cinit=False):
         emit_mfma(o, m)
     o.e("s_nop 15")
     o.e("s_nop 7")
-    o.c("tile 0: maxima define the first running maxima (no rescale: O = 0, l = 0)")
+    o.c("tile 0: its maxima become the running maxima; accumulators and -m blocks are shifted to them")
     for ln in max_stream(0):
         o.e(ln)
-    for qb in range(2):
-        o.e(f"v_mul_f32 v{T[0]}, s{S_C}, v{TM[qb]}")
-        o.e(f"v_sub_f32 v{T[0]}, 0, v{T[0]}")
-        o.e(f"v_min_f32 v{NM[qb]}, {POS_BIG}, v{T[0]}")
-        o.e(f"v_mov_b32 v{NM[qb] + 1}, v{NM[qb]}")
+    first_tile_max(o)
     for ln in k_reads(1):
         o.e(ln)
-    for x in exp_stream(0, 0):
-        o.e(x[1] if isinstance(x, tuple) else x)
+    for x in plain(exps_p2(0)):
+        o.e(x)
     lk: list[str] = []
     table_lookup(lk, 24, 8)          # next iteration j = 1 fetches K(3) and V(1); s_j is still 0 here
     for ln in lk:
@@ -602,8 +635,8 @@ def gen_body(o: Out, p):
     o.label(f".Lpf_body{p}")
     mask_setup(o, p, tag)
     # ---- phase 1 ----
-    vr = v_reads(q)
-    ex = exp_stream(q, 1)
+    vr = v_reads(q, [0, 1])
+    ex = plain(exps_p1(q))
     # V(j) and K(j+2) go to slot p.  The tile that holds the end of the sequence switches the wave's
     # source offsets to the clamped set (rare, checked here: branches stay out of the MFMA stream).
     # K(j+2) may lie behind the last tile: its table entry then repeats the last tile (a harmless fetch
@@ -618,59 +651,57 @@ def gen_body(o: Out, p):
     dma += [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}", f"s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
     dma += dma_pieces("K", p, DOFFK)
     fill1: list = []
-    # merge: fetches first, V reads early (needed at the start of phase 2), exponentials throughout
     vi = di = 0
     for k, x in enumerate(ex):
-        fill1.append(x[1] if isinstance(x, tuple) else x)
-        if k % 2 == 1 and di < len(dma):
+        fill1.append(x)
+        if k % 3 == 1 and di < len(dma):
             fill1.append(dma[di])
             di += 1
-        if k % VR_MOD[0] == VR_MOD[1] and vi < len(vr):
+        if k % 4 == 2 and vi < len(vr):
             fill1.append(vr[vi])
             vi += 1
     fill1 += dma[di:] + vr[vi:]
     interleave(o, qk_mfmas(p, f".Lpf_mm_{tag}"), fill1, tag + "p1")
     o.e("s_waitcnt lgkmcnt(0)")
-    # ---- phase 2 ----
-    fill2: list = []
+    # ---- phase 2: O += V(j-1)^T P(j-1) in four k-steps of 8 MFMAs ----
+    pv = pv_mfmas()
     mx = max_stream(p)
     kr = k_reads(q)
-    # maxima first (kb = 0 registers lead; the last S accumulator was written by the final MFMA of
-    # phase 1 and is read more than 16 instructions later), K reads beside them
+    ex2 = exps_p2(p)
+    # (a) MFMAs 0..9: the row maxima of S(j) (the last S accumulator was written by the final MFMA of phase 1
+    #     and is read more than 16 instructions later), some K reads
+    fa: list = []
     ki = 0
     for k, x in enumerate(mx):
-        fill2.append(x)
-        if k % 3 == 2 and ki < len(kr):
-            fill2.append(kr[ki])
+        fa.append(x)
+        if k % 6 == 5 and ki < 6:
+            fa.append(kr[ki])
             ki += 1
-    o2 = Out()
-    interleave_phase2(o, p, q, fill2, kr[ki:], tag)
-
-
-def interleave_phase2(o: Out, p, q, head, rest_kreads, tag):
-    """Phase 2 is emitted in two parts because the rescale decision (a branch) sits between the maxima and
-    the exponentials: MFMAs 0..n_head-1 carry the maxima, the rest carry exponentials / packing."""
-    pv = pv_mfmas()
-    n_head = N_HEAD
-    interleave(o, pv[:n_head], head, tag + "p2a")
-    slow_max(o, tag)
-    tail: list = []
-    ex = exp_stream(p, 0)
-    ki = 0
-    for k, x in enumerate(ex):
-        if isinstance(x, tuple):
-            # P fragments of k-steps 0, 1 are operands of the first 16 PV MFMAs of this phase
-            tail.append((16 - n_head, x[1]))
-        else:
-            tail.append(x)
-        if k % 6 == 5 and ki < len(rest_kreads):
-            tail.append(rest_kreads[ki])
-            ki += 1
-    tail += rest_kreads[ki:]
+    interleave(o, pv[0:10], fa, tag + "p2a")
+    slow_max(o, p, tag)
+    # (b) MFMAs 10..15: k-step 2 of V(j-1) into the registers of k-step 0 (its MFMAs 0..7 have issued), the
+    #     start of the exp stream; the P fragments of k-steps 0, 1 are still being read: packing waits
+    n_b = 18
+    eb = [x for x in ex2[:n_b] if not isinstance(x, tuple)]
+    late = [x[1] for x in ex2[:n_b] if isinstance(x, tuple)]
+    start = len(o.lines)
+    vr2 = v_reads(q, [2])
+    interleave(o, pv[10:16], vr2 + eb, tag + "p2b")
+    o.e(f"s_waitcnt lgkmcnt({lds_ops_after(o.lines[start:], vr2[-1])})")
+    # (c) MFMAs 16..23: k-step 3 into the registers of k-step 1, packing, more of the exp stream, K reads
+    rest = plain(ex2[n_b:])
+    n_c = (len(rest) + len(late)) * 8 // 16
+    fc = late + rest[:max(0, n_c - len(late))]
+    fd = rest[max(0, n_c - len(late)):]
+    start = len(o.lines)
+    vr3 = v_reads(q, [3])
+    interleave(o, pv[16:24], vr3 + fc + kr[ki:ki + 4], tag + "p2c")
+    ki += 4
+    o.e(f"s_waitcnt lgkmcnt({lds_ops_after(o.lines[start:], vr3[-1])})")
+    # (d) MFMAs 24..31: the rest, the K reads, the addresses of the next tiles
     lk: list[str] = []
     table_lookup(lk, 24, 8)          # iteration j+1 fetches K(j+3) and V(j+1); s_j is still j here
-    tail += lk
-    interleave(o, pv[n_head:], tail, tag + "p2b")
+    interleave(o, pv[24:32], fd + kr[ki:] + lk, tag + "p2d")
     o.e("s_waitcnt lgkmcnt(0)")
     rescale_check(o, tag)
     o.e("s_waitcnt vmcnt(0)")
@@ -682,15 +713,33 @@ def interleave_phase2(o: Out, p, q, head, rest_kreads, tag):
         o.e("s_branch .Lpf_body1")
 
 
+
+
+
 def gen_epilogue(o: Out, qbuf):
-    """After the last tile of an item (it sits in buffer qbuf): finish its softmax, read its V; then every
-    wave is done with the tile ring, so tiles 0 / 1 of the NEXT item are fetched while the last products
-    and the output stores run."""
+    """After the last tile of an item (it sits in buffer qbuf): finish its softmax and run its products; once
+    every wave has read the tile's last V k-step the ring is free, and tiles 0 / 1 of the NEXT item are fetched
+    while the last products and the output stores run."""
     o.label(f".Lpf_epi{qbuf}")
-    for ln in v_reads(qbuf):
+    for ln in v_reads(qbuf, [0, 1]):
         o.e(ln)
-    for x in exp_stream(qbuf, 1):
-        o.e(x[1] if isinstance(x, tuple) else x)
+    for x in plain(exps_p1(qbuf)):
+        o.e(x)
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e("s_nop 1")
+    pv = pv_mfmas()
+    for m in pv[0:9]:
+        o.e(m)
+    for ln in v_reads(qbuf, [2]):
+        o.e(ln)
+    for m in pv[9:16]:
+        o.e(m)
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e(pv[16])
+    for ln in v_reads(qbuf, [3]):
+        o.e(ln)
+    for m in pv[17:24]:
+        o.e(m)
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_barrier")
     o.e(f"s_add_u32 s{S_LAST}, s{S_ITEM}, 1")
@@ -710,7 +759,7 @@ def gen_epilogue(o: Out, qbuf):
     q_fetch(o, S_T0 + 1, K(0, 0))
     o.label(f".Lpf_epi{qbuf}_nonext")
     o.e("s_nop 3")
-    for m in pv_mfmas():
+    for m in pv[24:32]:
         o.e(m)
     o.e("s_branch .Lpf_fin")
 
