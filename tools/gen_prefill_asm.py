@@ -158,6 +158,8 @@ def k_reads(slot):
 
 
 N_P2 = int(os.environ.get("PF_NP2", "11"))   # value pairs of key block 0 whose exp stream runs in phase 2
+N_B = int(os.environ.get("PF_NB", "18"))     # entries of that stream that run beside MFMAs 10..15
+P1_DMA, P1_VR = (int(x) for x in os.environ.get("PF_P1MIX", "3,4").split(","))   # phase 1: a DMA / V read every n-th entry
 
 
 def exp_pairs(buf, kb):
@@ -646,18 +648,20 @@ def gen_body(o: Out, p):
     tail_fix(o, S_T0, DOFFK, f"{tag}_k")
     dma = [f"v_readfirstlane_b32 s{S_T0 + 6}, v254", f"v_readfirstlane_b32 s{S_T0 + 7}, v255",
            f"v_readfirstlane_b32 s{S_T0 + 2}, v252", f"v_readfirstlane_b32 s{S_T0 + 3}, v253",
-           f"s_add_u32 s54, s{S_VBASE}, s{S_T0 + 6}", f"s_addc_u32 s55, s{S_VBASE + 1}, s{S_T0 + 7}"]
+           # one filler (two instructions): nothing that writes SCC (the chain-start compare of an MFMA) may
+           # come between the add and the add-with-carry
+           f"s_add_u32 s54, s{S_VBASE}, s{S_T0 + 6}\n  s_addc_u32 s55, s{S_VBASE + 1}, s{S_T0 + 7}"]
     dma += dma_pieces("V", p, DOFFV)
-    dma += [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}", f"s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
+    dma += [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}\n  s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
     dma += dma_pieces("K", p, DOFFK)
     fill1: list = []
     vi = di = 0
     for k, x in enumerate(ex):
         fill1.append(x)
-        if k % 3 == 1 and di < len(dma):
+        if k % P1_DMA == 1 and di < len(dma):
             fill1.append(dma[di])
             di += 1
-        if k % 4 == 2 and vi < len(vr):
+        if k % P1_VR == 2 % P1_VR and vi < len(vr):
             fill1.append(vr[vi])
             vi += 1
     fill1 += dma[di:] + vr[vi:]
@@ -681,7 +685,7 @@ def gen_body(o: Out, p):
     slow_max(o, p, tag)
     # (b) MFMAs 10..15: k-step 2 of V(j-1) into the registers of k-step 0 (its MFMAs 0..7 have issued), the
     #     start of the exp stream; the P fragments of k-steps 0, 1 are still being read: packing waits
-    n_b = 18
+    n_b = N_B
     eb = [x for x in ex2[:n_b] if not isinstance(x, tuple)]
     late = [x[1] for x in ex2[:n_b] if isinstance(x, tuple)]
     start = len(o.lines)
@@ -850,7 +854,31 @@ def generate() -> str:
     for blk in _ool:
         o.lines += blk
     o.label(".Lpf_end")
-    return "\n".join(o.lines) + "\n"
+    text = "\n".join(o.lines) + "\n"
+    check_scc(text)
+    return text
+
+
+_SCC_WRITERS = ("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_ashr", "s_bfe", "s_min",
+                "s_max", "s_abs", "s_not")
+
+
+def check_scc(text: str):
+    """Static check of the generated code: every add-with-carry directly follows its add, and every branch on
+    SCC (and s_cselect) directly follows the instruction that sets SCC.  The interleaver places instructions
+    between others; a compare that slipped between an s_add_u32 and its s_addc_u32 once sent a DMA 4 GiB off."""
+    ins = [ln.strip() for ln in text.splitlines() if ln.startswith("  ") and not ln.strip().startswith(";")]
+    lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+    for i, ln in enumerate(lines):
+        op = ln.split()[0]
+        if op in ("s_addc_u32", "s_cselect_b32") or op.startswith("s_cbranch_scc"):
+            prev = lines[i - 1]
+            ok = prev.split()[0].startswith(_SCC_WRITERS) and not prev.endswith(":")
+            if op == "s_cbranch_scc1" and prev.split()[0] == "s_cselect_b32":
+                ok = True           # s_cselect reads SCC and leaves it
+            if not ok:
+                raise AssertionError(f"SCC consumer '{ln}' does not directly follow its producer (found '{prev}')")
+    return len(ins)
 
 
 def clobbers() -> str:
