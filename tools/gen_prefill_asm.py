@@ -105,7 +105,7 @@ def rng(kind, base, n):
 
 
 # ---- instruction streams -------------------------------------------------------------------------
-def qk_mfmas(buf, masked_label_prefix, cinit=True):
+def qk_mfmas(buf, masked_label_prefix, cinit=True, mode="branch"):
     """32 MFMAs S^T[kb][qb] = sum_s K[kb][s] Q[qb][s] (+ C); a chain starts from the -m block of its query
     rows (cinit) or from 0 (first tile of an item), or, when the tile is masked, from the preset mask tile
     through an out-of-line copy.  Returns a list of (kind, d, a, b, label, c)."""
@@ -119,7 +119,8 @@ def qk_mfmas(buf, masked_label_prefix, cinit=True):
                 b = rng("a", Q(qb, s), 4)
                 if s == 0:
                     c = rng("v", NMB(qb), 16) if cinit else "0"
-                    ms.append(("start", d, a, b, f"{masked_label_prefix}_{n}", c))
+                    kind = {"branch": "start", "plain": "start_plain", "masked": "start_masked"}[mode]
+                    ms.append((kind, d, a, b, f"{masked_label_prefix}_{n}", c))
                     n += 1
                 else:
                     ms.append(("acc", d, a, b, None, None))
@@ -301,8 +302,11 @@ def emit_mfma(o: Out, m):
         o.e(m)
         return
     kind, d, a, b, lab, c = m
-    if kind == "acc":
+    if kind in ("acc", "start_masked"):
         o.e(f"{MFMA} {d}, {a}, {b}, {d}")
+        return
+    if kind == "start_plain":
+        o.e(f"{MFMA} {d}, {a}, {b}, {c}")
         return
     # chain start: C = the -m block (or 0), or C = the mask tile already sitting in the accumulator registers
     o.e(f"s_cmp_lg_u32 s{S_MASKED}, 0")
@@ -313,13 +317,17 @@ def emit_mfma(o: Out, m):
 
 
 # ---- building blocks -------------------------------------------------------------------------------
-def mask_setup(o: Out, buf, tag, first=False):
-    """s_masked = (j >= mask_from); a masked tile presets S(buf) with -m (visible; 0 for the first tile of an
-    item, whose chains start from 0) / -inf (hidden)."""
+def mask_setup(o: Out, buf, tag, first=False, masked_phase=None):
+    """A masked tile (j >= mask_from) presets S(buf) with -m (visible; 0 for the first tile of an item, whose
+    chains start from 0) / -inf (hidden).  first: s_masked tells the chain starts which C to take and the
+    block returns; otherwise the block continues into `masked_phase`, its own copy of phase 1 whose chains
+    start from the preset tile (lines; it ends with a branch to the common phase 2)."""
     o.e(f"s_cmp_ge_u32 s{S_J}, s{S_MASKFROM}")
-    o.e(f"s_cselect_b32 s{S_MASKED}, 1, 0")
+    if masked_phase is None:
+        o.e(f"s_cselect_b32 s{S_MASKED}, 1, 0")
     o.e(f"s_cbranch_scc1 .Lpf_mask_{tag}")
-    o.label(f".Lpf_mask_{tag}_ret")
+    if masked_phase is None:
+        o.label(f".Lpf_mask_{tag}_ret")
     blk = [f".Lpf_mask_{tag}:", f"  s_lshl_b32 s{S_T0}, s{S_J}, 6"]
     for qb in range(2):
         blk.append(f"  v_subrev_u32 v{T[qb]}, s{S_T0}, v{QPOS[qb]}")
@@ -336,7 +344,10 @@ def mask_setup(o: Out, buf, tag, first=False):
                     blk.append(f"  v_cndmask_b32 v{S(buf, kb, qb, i0 + k)}, v{NINF}, {vis}, "
                                f"s[{S_CMP + 2 * k}:{S_CMP + 2 * k + 1}]")
     blk.append("  s_nop 3")
-    blk.append(f"  s_branch .Lpf_mask_{tag}_ret")
+    if masked_phase is None:
+        blk.append(f"  s_branch .Lpf_mask_{tag}_ret")
+    else:
+        blk += masked_phase
     _ool.append(blk)
 
 
@@ -419,7 +430,10 @@ def first_tile_max(o: Out):
 
 def lds_ops_after(lines, marker):
     """Number of LDS instructions in `lines` behind the last line that contains `marker`."""
-    last = max(i for i, ln in enumerate(lines) if marker in ln)
+    hits = [i for i, ln in enumerate(lines) if marker in ln]
+    if not hits:                     # timing-only builds may have dropped the reads
+        return 0
+    last = hits[-1]
     return sum(1 for ln in lines[last + 1:] if ln.strip().startswith("ds_"))
 
 
@@ -635,7 +649,6 @@ def gen_body(o: Out, p):
     q = 1 - p
     tag = f"b{p}"
     o.label(f".Lpf_body{p}")
-    mask_setup(o, p, tag)
     # ---- phase 1 ----
     vr = v_reads(q, [0, 1])
     ex = plain(exps_p1(q))
@@ -648,8 +661,8 @@ def gen_body(o: Out, p):
     tail_fix(o, S_T0, DOFFK, f"{tag}_k")
     dma = [f"v_readfirstlane_b32 s{S_T0 + 6}, v254", f"v_readfirstlane_b32 s{S_T0 + 7}, v255",
            f"v_readfirstlane_b32 s{S_T0 + 2}, v252", f"v_readfirstlane_b32 s{S_T0 + 3}, v253",
-           # one filler (two instructions): nothing that writes SCC (the chain-start compare of an MFMA) may
-           # come between the add and the add-with-carry
+           # one filler (two instructions): nothing that writes SCC may come between the add and the
+           # add-with-carry
            f"s_add_u32 s54, s{S_VBASE}, s{S_T0 + 6}\n  s_addc_u32 s55, s{S_VBASE + 1}, s{S_T0 + 7}"]
     dma += dma_pieces("V", p, DOFFV)
     dma += [f"s_add_u32 s54, s{S_KBASE}, s{S_T0 + 2}\n  s_addc_u32 s55, s{S_KBASE + 1}, s{S_T0 + 3}"]
@@ -665,20 +678,32 @@ def gen_body(o: Out, p):
             fill1.append(vr[vi])
             vi += 1
     fill1 += dma[di:] + vr[vi:]
-    interleave(o, qk_mfmas(p, f".Lpf_mm_{tag}"), fill1, tag + "p1")
+    # two copies of phase 1: the common one starts its S chains from the -m blocks; the one for masked tiles
+    # (out of line, behind the block that presets S) starts them from S itself.  One branch per tile.
+    om = Out()
+    om.hot = o.hot
+    interleave(om, qk_mfmas(p, f".Lpf_mm_{tag}", mode="masked"), fill1, tag + "p1m")
+    om.e(f"s_branch .Lpf_p2_{tag}")
+    mask_setup(o, p, tag, masked_phase=om.lines)
+    interleave(o, qk_mfmas(p, f".Lpf_mm_{tag}", mode="plain"), fill1, tag + "p1")
+    o.label(f".Lpf_p2_{tag}")
     o.e("s_waitcnt lgkmcnt(0)")
     # ---- phase 2: O += V(j-1)^T P(j-1) in four k-steps of 8 MFMAs ----
     pv = pv_mfmas()
     mx = max_stream(p)
     kr = k_reads(q)
     ex2 = exps_p2(p)
-    # (a) MFMAs 0..9: the row maxima of S(j) (the last S accumulator was written by the final MFMA of phase 1
-    #     and is read more than 16 instructions later), some K reads
-    fa: list = []
+    # (a) MFMAs 0..9: the addresses of the next tiles (v[252:255] are free once phase 1 has taken this tile's),
+    #     the row maxima of S(j) (the last S accumulator was written by the final MFMA of phase 1 and is read
+    #     more than 16 instructions later), half of the K reads.  LDS reads go first in every part: the wait
+    #     at the end of the tile should find them done.
+    lk: list[str] = []
+    table_lookup(lk, 24, 8)          # iteration j+1 fetches K(j+3) and V(j+1); s_j is still j here
+    fa: list = list(lk)
     ki = 0
     for k, x in enumerate(mx):
         fa.append(x)
-        if k % 6 == 5 and ki < 6:
+        if k % 4 == 3 and ki < 8:
             fa.append(kr[ki])
             ki += 1
     interleave(o, pv[0:10], fa, tag + "p2a")
@@ -692,20 +717,18 @@ def gen_body(o: Out, p):
     vr2 = v_reads(q, [2])
     interleave(o, pv[10:16], vr2 + eb, tag + "p2b")
     o.e(f"s_waitcnt lgkmcnt({lds_ops_after(o.lines[start:], vr2[-1])})")
-    # (c) MFMAs 16..23: k-step 3 into the registers of k-step 1, packing, more of the exp stream, K reads
+    # (c) MFMAs 16..23: k-step 3 into the registers of k-step 1, K reads, packing, more of the exp stream
     rest = plain(ex2[n_b:])
     n_c = (len(rest) + len(late)) * 8 // 16
     fc = late + rest[:max(0, n_c - len(late))]
     fd = rest[max(0, n_c - len(late)):]
     start = len(o.lines)
     vr3 = v_reads(q, [3])
-    interleave(o, pv[16:24], vr3 + fc + kr[ki:ki + 4], tag + "p2c")
+    interleave(o, pv[16:24], vr3 + kr[ki:ki + 4] + fc, tag + "p2c")
     ki += 4
     o.e(f"s_waitcnt lgkmcnt({lds_ops_after(o.lines[start:], vr3[-1])})")
-    # (d) MFMAs 24..31: the rest, the K reads, the addresses of the next tiles
-    lk: list[str] = []
-    table_lookup(lk, 24, 8)          # iteration j+1 fetches K(j+3) and V(j+1); s_j is still j here
-    interleave(o, pv[24:32], fd + kr[ki:] + lk, tag + "p2d")
+    # (d) MFMAs 24..31: the last K reads, the rest of the exp stream
+    interleave(o, pv[24:32], kr[ki:] + fd, tag + "p2d")
     o.e("s_waitcnt lgkmcnt(0)")
     rescale_check(o, tag)
     o.e("s_waitcnt vmcnt(0)")
