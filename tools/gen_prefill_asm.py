@@ -882,26 +882,15 @@ def generate() -> str:
     return text
 
 
-_SCC_WRITERS = ("s_cmp", "s_add", "s_sub", "s_and", "s_or", "s_xor", "s_lshl", "s_lshr", "s_ashr", "s_bfe", "s_min",
-                "s_max", "s_abs", "s_not")
-
-
 def check_scc(text: str):
-    """Static check of the generated code: every add-with-carry directly follows its add, and every branch on
-    SCC (and s_cselect) directly follows the instruction that sets SCC.  The interleaver places instructions
-    between others; a compare that slipped between an s_add_u32 and its s_addc_u32 once sent a DMA 4 GiB off."""
-    ins = [ln.strip() for ln in text.splitlines() if ln.startswith("  ") and not ln.strip().startswith(";")]
-    lines = [ln.strip() for ln in text.splitlines() if ln.strip() and not ln.strip().startswith(";")]
-    for i, ln in enumerate(lines):
-        op = ln.split()[0]
-        if op in ("s_addc_u32", "s_cselect_b32") or op.startswith("s_cbranch_scc"):
-            prev = lines[i - 1]
-            ok = prev.split()[0].startswith(_SCC_WRITERS) and not prev.endswith(":")
-            if op == "s_cbranch_scc1" and prev.split()[0] == "s_cselect_b32":
-                ok = True           # s_cselect reads SCC and leaves it
-            if not ok:
-                raise AssertionError(f"SCC consumer '{ln}' does not directly follow its producer (found '{prev}')")
-    return len(ins)
+    """Static checks of the generated code (tools/check_prefill_asm.py): SCC consumers directly behind their
+    producers, no use of a register with a load outstanding into it, no early use of MFMA results.  The
+    interleaver places instructions between others, so these are checked on its output."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import check_prefill_asm
+    errs = check_prefill_asm.check(text)
+    if errs:
+        raise AssertionError("generated loop fails the static checks:\n  " + "\n  ".join(errs[:20]))
 
 
 def clobbers() -> str:
