@@ -44,3 +44,17 @@ def test_checker_finds_an_early_read_of_an_mfma_result_and_counted_waits():
                          "  v_mfma_f32_32x32x16_bf16 a[0:15], v[128:131], v[192:195], a[0:15]"])
     assert check_prefill_asm.check(counted) == []
     assert check_prefill_asm.check(counted.replace("lgkmcnt(1)", "lgkmcnt(2)")) != []
+
+
+def test_checker_short_distance_rules():
+    c = check_prefill_asm.check
+    assert any("transcendental" in e for e in c("  v_exp_f32 v0, v0\n  v_add_f32 v226, v226, v0"))
+    assert c("  v_exp_f32 v0, v0\n  v_exp_f32 v1, v1\n  v_add_f32 v226, v226, v0") == []
+    assert any("two slots" in e for e in c("  v_mov_b32 v250, v230\n  v_permlane32_swap_b32 v230, v250"))
+    assert c("  v_mov_b32 v250, v230\n  s_nop 1\n  v_permlane32_swap_b32 v230, v250") == []
+    assert any("in front of it wrote" in e for e in c("  v_mov_b32 v252, v1\n  v_readfirstlane_b32 s52, v252"))
+    bad = "  v_readfirstlane_b32 s54, v252\n  v_readfirstlane_b32 s55, v253\n  global_load_lds_dwordx4 v236, s[54:55] offset:0"
+    assert any("five slots" in e for e in c(bad))
+    ok = ("  v_readfirstlane_b32 s52, v252\n  v_readfirstlane_b32 s53, v253\n  s_add_u32 s54, s36, s52\n"
+          "  s_addc_u32 s55, s37, s53\n  s_add_u32 m0, s47, 0\n  s_nop 0\n  global_load_lds_dwordx4 v236, s[54:55] offset:0")
+    assert c(ok) == []

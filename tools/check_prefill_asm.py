@@ -10,6 +10,10 @@ checked on its OUTPUT:
      read into its own address register takes the loaded word for an address once its issue is held back).
   3. MFMA results: an instruction other than an MFMA that accumulates into the same registers may touch the
      destination registers of an MFMA only MFMA_WAIT instruction slots later.
+  4. Short fixed distances: the result of a transcendental instruction is not read by the next instruction; a
+     register written by a vector instruction is read by v_permlane32_swap at the earliest two slots later and
+     by v_readfirstlane one slot later; a scalar register written by a vector instruction (v_readfirstlane,
+     v_cmp) is used by a memory instruction as address base at the earliest five slots later.
 
 The walk is linear over the text.  A label that is only reached by branches starts from the union of the states
 at the branches to it; a label reached by falling through joins that union with the fall-through state.
@@ -86,6 +90,56 @@ def parse(line: str):
     return op, set(), set(), "scalar"
 
 
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+_TRANS = ("v_exp_f32", "v_rcp_f32", "v_log_f32", "v_sqrt_f32", "v_rsq_f32")
+
+
+def sregs_of(text: str) -> set:
+    out = set()
+    for m in _SREG.finditer(text):
+        if m.group(1):
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check_short_distances(lines: list) -> list:
+    """Check 4 (linear; labels and branches reset the history: the code behind them does not depend on
+    results produced right in front of them)."""
+    errors = []
+    hist: list = []          # (slots ago is implied by position) entries: (op, vector dst, scalar dst)
+    for i, ln in enumerate(lines):
+        if ln.endswith(":") or ln.split()[0] in ("s_branch",) or ln.split()[0].startswith("s_cbranch"):
+            hist = []
+            continue
+        op, dst, src, kind = parse(ln)
+        if op == "s_nop":
+            hist += [("s_nop", set(), set())] * (int(ln.split()[1]) + 1)
+            continue
+        ops = split_operands(ln.split(None, 1)[1]) if " " in ln else []
+        sdst = sregs_of(ops[0]) if ops and op.startswith(("v_readfirstlane", "v_cmp")) else set()
+
+        def written_within(n, regs, vector=True):
+            for back, (hop, hv, hs) in enumerate(reversed(hist[-n:]) if n else []):
+                if hop.startswith("v_") and ((hv if vector else hs) & regs):
+                    return hop
+            return None
+        if hist and hist[-1][0].startswith(_TRANS) and (hist[-1][1] & src):
+            errors.append(f"line {i}: '{ln}' reads the result of the transcendental instruction right in front of it")
+        if op.startswith("v_permlane") and written_within(2, src):
+            errors.append(f"line {i}: '{ln}' reads a register a vector instruction wrote less than two slots before")
+        if op.startswith("v_readfirstlane") and written_within(1, src):
+            errors.append(f"line {i}: '{ln}' reads a register the instruction in front of it wrote")
+        if kind in ("vm_load", "vm_other"):
+            base = sregs_of(" ".join(ops))
+            if written_within(5, base, vector=False):
+                errors.append(f"line {i}: '{ln}' uses a scalar register a vector instruction wrote less than five slots before")
+        hist.append((op, set(dst), sdst))
+        hist = hist[-8:]
+    return errors
+
+
 class State:
     def __init__(self):
         self.lgkm: list = []      # outstanding LDS ops in issue order: sets of destination registers (may be empty)
@@ -123,6 +177,7 @@ def check(text: str) -> list:
                 ok = True
             if not ok:
                 errors.append(f"line {i}: SCC consumer '{ln}' does not directly follow its producer ('{prev}')")
+    errors += check_short_distances(lines)
     # ---- 2 / 3. outstanding loads and MFMA results ----
     at_label: dict = {}
     st = State()
