@@ -420,21 +420,33 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     // equal at 8 and 9 - 13 % faster from 16 tiles on.
     prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 64);
     const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
-    sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : (big_wgs >= 256 && tiles >= 16);
+    // with fewer workgroups than CUs it splits the key range like the other kernel does (one workgroup per
+    // CU, at least 16 tiles per split) and leaves unnormalised states for the merge kernel
+    int ns_asm = 1;
+    if (tn.prefill_split > 0) {
+        ns_asm = tn.prefill_split;
+    } else if (big_wgs < 256) {
+        ns_asm = (int)(256 / big_wgs);
+        if (ns_asm > tiles / 16) ns_asm = tiles / 16;
+        if (ns_asm < 1) ns_asm = 1;
+    }
+    const bool asm_fills_chip = big_wgs >= 256 || (ns_asm >= 2 && big_wgs * ns_asm >= 128);
+    sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : (asm_fills_chip && tiles >= 16);
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
     sh.pair_items = false;
     if (sh.hand_scheduled) {
+        if (ns_asm > tiles) ns_asm = tiles > 0 ? tiles : 1;
+        sh.tiles_per_split = tiles > 0 ? (tiles + ns_asm - 1) / ns_asm : 1;
+        sh.nsplit = ns_asm > 1 ? (tiles + sh.tiles_per_split - 1) / sh.tiles_per_split : 1;
         // two query tiles per workgroup (equal work for all workgroups of a sequence, half the fixed
         // per-workgroup cost) while that still leaves two workgroups per CU
         const int slots = (sh.n_qtiles + 1) / 2;
-        if ((int64_t)sh.n_pairs * slots * (sh.wg_per_pair / sh.n_qtiles) >= 512) {
+        if (sh.nsplit == 1 && (int64_t)sh.n_pairs * slots * (sh.wg_per_pair / sh.n_qtiles) >= 512) {
             sh.pair_items = true;
             sh.wg_per_pair = slots * (sh.wg_per_pair / sh.n_qtiles);
             sh.n_qtiles = slots;
             sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
         }
-        sh.nsplit = 1;
-        sh.tiles_per_split = tiles > 0 ? tiles : 1;
         return sh;
     }
     prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 32);
@@ -536,12 +548,14 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     const int64_t grid = sh.grid_base * sh.nsplit;
     NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
     hipStream_t st = (hipStream_t)stream;
+    int rc;
     if (sh.hand_scheduled) {
         launch_prefill_asm(p, grid, st);
-        return check_launch("nv_attn_prefill_varlen(hand-scheduled)");
+        rc = check_launch("nv_attn_prefill_varlen(hand-scheduled)");
+    } else {
+        hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
+        rc = check_launch("nv_attn_prefill_varlen");
     }
-    hipLaunchKernelGGL(attn_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, st, p);
-    int rc = check_launch("nv_attn_prefill_varlen");
     if (rc != NV_OK || sh.nsplit == 1) return rc;
     hipLaunchKernelGGL(attn_prefill_merge_kernel,
                        dim3((unsigned)(((int64_t)max_seqlen_q * H_q + 7) / 8), (unsigned)B),

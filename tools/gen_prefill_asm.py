@@ -67,6 +67,7 @@ S_NT, S_J, S_C, S_TAIL, S_MASKFROM, S_MASKED, S_RESC, S_PIECE, S_STG, S_TBL = 40
 S_T0 = 50                      # s50..s57 temporaries
 S_CMP = 60                     # s[60:67] compare results
 S_DESC, S_NITEMS, S_ITEM = 68, 69, 70      # LDS address of the wave's item descriptors, item count, current item
+S_MODE = 71                    # 0: bf16 output rows; 1: unnormalised fp32 states of a key range (128 + m + l per row)
 S_QSEQ, S_OSEQ = 72, 74        # 64-bit: row 0 of this wave's query head in q / in o (of the sequence)
 S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
 S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
@@ -542,7 +543,7 @@ def lane_consts(o: Out):
 def gen_setup(o: Out):
     o.c("---- once per workgroup: operands to fixed registers, lane constants ----")
     ops = [(S_KBASE, 64), (S_VBASE, 64), (S_C, 32), (S_TAIL, 32), (S_PIECE, 32), (S_STG, 32), (S_TBL, 32),
-           (S_DESC, 32), (S_NITEMS, 32), (S_QSEQ, 64), (S_OSEQ, 64), (S_QSTR, 32), (S_OSTR, 32), (S_NQ1, 32)]
+           (S_DESC, 32), (S_NITEMS, 32), (S_QSEQ, 64), (S_OSEQ, 64), (S_QSTR, 32), (S_OSTR, 32), (S_NQ1, 32), (S_MODE, 32)]
     for i, (r, bits) in enumerate(ops):
         if bits == 64:
             o.e(f"s_mov_b64 s[{r}:{r + 1}], %{i}")
@@ -791,6 +792,37 @@ def gen_epilogue(o: Out, qbuf):
     o.e("s_branch .Lpf_fin")
 
 
+def partial_state_store():
+    """Key-range split: the wave's rows leave as unnormalised fp32 states [128 accumulators, m, l] (row stride
+    s_ostr bytes), 16 bytes per lane and store (lane (r, h) holds dims 32 d + 8 g + 4 h .. + 3 of row 32 qb + r).
+    Out of line; v[0:67] are free here."""
+    b = [".Lpf_fin_part:"]
+    b += [f"  s_mul_i32 s{S_T0}, s{S_RW0}, s{S_OSTR}", f"  s_mul_hi_u32 s{S_T0 + 1}, s{S_RW0}, s{S_OSTR}",
+          f"  s_add_u32 s{S_T0 + 2}, s{S_OSEQ}, s{S_T0}", f"  s_addc_u32 s{S_T0 + 3}, s{S_OSEQ + 1}, s{S_T0 + 1}",
+          f"  v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0", f"  v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}",
+          f"  v_and_b32 v{T[4]}, 31, v{T[0]}", f"  v_lshrrev_b32 v{T[5]}, 5, v{T[0]}", f"  v_lshlrev_b32 v{T[5]}, 4, v{T[5]}"]
+    k = 0
+    for qb in range(2):
+        b += [f"  v_add_u32 v{T[1]}, {32 * qb}, v{T[4]}",                              # row of the lane
+              f"  v_mul_u32_u24 v{T[2]}, v{T[1]}, s{S_OSTR}",                          # its byte offset
+              f"  v_add_u32 v{T[3]}, v{T[2]}, v{T[5]}",                                # + 16 h
+              f"  v_sub_f32 v{64 + 2 * qb}, 0, v{NMB(qb)}", f"  v_mov_b32 v{65 + 2 * qb}, v{L[qb]}",
+              f"  v_cmp_gt_i32 vcc, s{S_ROWS}, v{T[1]}",
+              f"  s_and_saveexec_b64 s[{S_SAVE}:{S_SAVE + 1}], vcc"]
+        for d in range(4):
+            for g in range(4):
+                r0 = 4 * (k % 16)
+                k += 1
+                for i in range(4):
+                    b.append(f"  v_accvgpr_read_b32 v{r0 + i}, a{O(qb, d, 4 * g + i)}")
+                b.append("  s_nop 0")
+                b.append(f"  global_store_dwordx4 v{T[3]}, v[{r0}:{r0 + 3}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{d * 128 + g * 32}")
+        b.append(f"  global_store_dwordx2 v{T[2]}, v[{64 + 2 * qb}:{65 + 2 * qb}], s[{S_T0 + 2}:{S_T0 + 3}] offset:512")
+        b.append(f"  s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
+    b.append("  s_branch .Lpf_fin_next")
+    _ool.append(b)
+
+
 def gen_finish(o: Out):
     o.label(".Lpf_fin")
     o.c("denominators: add the share of the lane that holds the other half of each row; 1 / l (0 for rows without keys)")
@@ -805,6 +837,9 @@ def gen_finish(o: Out):
         o.e(f"v_permlane32_swap_b32 v{L[qb]}, v{T[qb]}")
     for qb in range(2):
         o.e(f"v_add_f32 v{L[qb]}, v{L[qb]}, v{T[qb]}")
+    o.e(f"s_cmp_lg_u32 s{S_MODE}, 0")
+    o.e("s_cbranch_scc1 .Lpf_fin_part")
+    partial_state_store()
     for qb in range(2):
         o.e(f"v_rcp_f32 v{AL[qb]}, v{L[qb]}")
         o.e(f"v_cmp_lt_f32 vcc, 0, v{L[qb]}")
@@ -853,6 +888,7 @@ def gen_finish(o: Out):
         o.e(f"global_store_dwordx4 v{T[4]}, v[{4 * it}:{4 * it + 3}], s[{S_T0 + 2}:{S_T0 + 3}]")
         o.e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
         o.e(f"v_add_u32 v{T[4]}, s{S_T0 + 5}, v{T[4]}")
+    o.label(".Lpf_fin_next")
     o.c("next item")
     o.e(f"s_add_u32 s{S_ITEM}, s{S_ITEM}, 1")
     o.e(f"s_cmp_ge_u32 s{S_ITEM}, s{S_NITEMS}")
