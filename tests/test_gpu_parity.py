@@ -529,12 +529,15 @@ def test_prefill_hand_scheduled_kernel_on_engine_step_shapes_with_guard_rows(hip
     assert launches == 100 and bad == 0
 
 
-def test_prefill_key_range_split_long_chunk(hip):
+@pytest.mark.parametrize("kernel", [-1, 0, 1])
+def test_prefill_key_range_split_long_chunk(hip, tuning, kernel):
     """One long sequence prefilled in a chunk: too few workgroups for the chip, so the launch splits
-    the key range over several workgroups and merges their states in a second launch."""
+    the key range over several workgroups and merges their states in a second launch (either kernel,
+    and whichever the launch plan picks)."""
     _, ops = hip
     from nanovllm_amd import _lib
     H_q, H_kv, n_q, n_k = 32, 8, 512, 4096
+    tuning(prefill_kernel=kernel)
     assert _lib.lib().nv_attn_prefill_workspace_bytes(1, n_q, n_q, n_k, H_q, H_kv, 128) > 16   # the split path is taken
     p = make_paged_problem(21, [n_q], [n_k], H_q, H_kv, 256, 17)
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
@@ -542,9 +545,10 @@ def test_prefill_key_range_split_long_chunk(hip):
     _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-split")
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("nsplit", [2, 3, 7])
-def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit):
-    """Forced split counts on a ragged mixed batch: splits that lie wholly above a row block's
+def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit, kernel):
+    """Forced split counts on a ragged mixed batch, both kernels: splits that lie wholly above a row block's
     diagonal are empty, sequences with one query stay with the decode kernel."""
     _, ops = hip
     n_qs, n_ks = [1, 70, 300, 5, 129], [40, 70, 700, 261, 1000]
@@ -552,7 +556,7 @@ def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit):
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
                                             p["block_tables"], p["scale"])
     pd = to_dev(p)
-    tuning(prefill_split=nsplit)
+    tuning(prefill_split=nsplit, prefill_kernel=kernel)
     _attn_check(_run_attention(ops, pd, "prefill"), ref, f"prefill-split{nsplit}")
     _attn_check(_run_attention(ops, pd, "mixed"), ref, f"mixed-split{nsplit}")
 
