@@ -515,6 +515,28 @@ def test_prefill_hand_scheduled_kernel_two_tiles_per_workgroup(hip, tuning, n_qs
     _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, "prefill-hand-pairs")
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_prefill_hand_scheduled_kernel_random_ragged_batches(hip, tuning, seed):
+    """Seeded random batches for the hand-scheduled kernel: 1 - 6 sequences, query chunks of 1 - 700 rows over
+    0 - 1500 cached keys, head shapes with 1, 2, 4 and 8 query heads per kv head, block size 64 or 256, and a
+    forced key-range split in every third case (empty ranges, ranges that end inside a tile)."""
+    _, ops = hip
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    H_kv = [1, 2, 4, 8][ri(0, 3)]
+    H_q = H_kv * [1, 2, 4, 8][ri(0, 3)]
+    bs = [64, 256][ri(0, 1)]
+    B = ri(1, 6)
+    n_qs = [ri(1, 700) if ri(0, 4) else ri(1, 3) for _ in range(B)]
+    n_ks = [nq + (ri(0, 1500) if ri(0, 2) else 0) for nq in n_qs]
+    nb = sum((n + bs - 1) // bs for n in n_ks) + 2
+    p = make_paged_problem(seed + 500, n_qs, n_ks, H_q, H_kv, bs, nb)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    tuning(prefill_kernel=1, prefill_split=[0, 0, 3][seed % 3])
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, f"hand-random-{seed}: H {H_q}/{H_kv} bs {bs} {n_qs} {n_ks}")
+
+
 def test_prefill_hand_scheduled_kernel_on_engine_step_shapes_with_guard_rows(hip):
     """The launches of an engine prefill step (16 / 8 heads, 8 - 10 ragged sequences, chunk tails of a few
     rows, q a strided slice of a fused qkv buffer, query offsets that do not start at 0), 100 launch pairs:
