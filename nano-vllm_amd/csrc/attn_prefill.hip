@@ -392,7 +392,7 @@ struct PrefillShape {
     int64_t grid_base;
     int nsplit, tiles_per_split;
     bool hand_scheduled;   // attn_prefill_asm_kernel (64 query rows per wave, never split) instead of attn_prefill_kernel
-    bool pair_items;       // its workgroups take two query tiles each (one from each end of the sequence)
+    int items_per_wg;      // its workgroups take 1, 2 or 4 query tiles each (chosen so that all have equal work)
 };
 
 // Workgroup shape and key-range split of a launch.  The key range is split only when the
@@ -433,19 +433,26 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     const bool asm_fills_chip = big_wgs >= 256 || (ns_asm >= 2 && big_wgs * ns_asm >= 128);
     sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1 : (asm_fills_chip && tiles >= 16);
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
-    sh.pair_items = false;
+    sh.items_per_wg = 1;
     if (sh.hand_scheduled) {
         if (ns_asm > tiles) ns_asm = tiles > 0 ? tiles : 1;
         sh.tiles_per_split = tiles > 0 ? (tiles + ns_asm - 1) / ns_asm : 1;
         sh.nsplit = ns_asm > 1 ? (tiles + sh.tiles_per_split - 1) / sh.tiles_per_split : 1;
-        // two query tiles per workgroup (equal work for all workgroups of a sequence, half the fixed
-        // per-workgroup cost) while that still leaves two workgroups per CU
-        const int slots = (sh.n_qtiles + 1) / 2;
-        if (sh.nsplit == 1 && (int64_t)sh.n_pairs * slots * (sh.wg_per_pair / sh.n_qtiles) >= 512) {
-            sh.pair_items = true;
-            sh.wg_per_pair = slots * (sh.wg_per_pair / sh.n_qtiles);
-            sh.n_qtiles = slots;
-            sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+        // several query tiles per workgroup (equal work for all workgroups of a sequence, a half or a quarter
+        // of the fixed per-workgroup cost: about 6 us until the first MFMA) while that still leaves two
+        // workgroups per CU
+        if (sh.nsplit == 1) {
+            const int groups = sh.wg_per_pair / sh.n_qtiles;
+            for (int m = 4; m >= 2; m /= 2) {
+                const int slots = (sh.n_qtiles + m - 1) / m;
+                if ((int64_t)sh.n_pairs * slots * groups >= 512) {
+                    sh.items_per_wg = m;
+                    sh.wg_per_pair = slots * groups;
+                    sh.n_qtiles = slots;
+                    sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+                    break;
+                }
+            }
         }
         return sh;
     }
@@ -538,7 +545,7 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.nsplit = sh.nsplit;
     p.tiles_per_split = sh.tiles_per_split;
     p.grid_base = (int)sh.grid_base;
-    p.pair_items = sh.pair_items ? 1 : 0;
+    p.pair_items = sh.items_per_wg;
     if (sh.nsplit > 1) {
         const int64_t need = (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
         NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,

@@ -37,7 +37,7 @@ struct PrefillParams {
     int nsplit;           // 1: results are written directly
     int tiles_per_split;  // 64-key tiles per split
     int grid_base;        // workgroups per split (multiple of 8)
-    int pair_items;       // hand-scheduled kernel: a workgroup takes two query tiles (one from each end)
+    int pair_items;       // hand-scheduled kernel: query tiles per workgroup (1, 2 or 4; balanced over the sequence)
 };
 
 // hand-scheduled kernel for large launches (attn_prefill_asm.hip): one wave per SIMD, 64 query rows per wave

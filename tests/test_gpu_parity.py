@@ -495,11 +495,13 @@ def test_prefill_hand_scheduled_kernel_rescale_and_nan_tails(hip, tuning):
     ([1024] * 16, [1024] * 16),                                   # 4 query tiles per head: pairs (3, 0), (2, 1)
     ([768] * 22, [768] * 22),                                     # 3 tiles: the middle one is a lone second item
     ([960, 1000, 64, 70] * 4, [960, 1300, 64, 326] * 4),          # ragged and chunked sequences in one launch
+    ([1024] * 32, [1024] * 32),                                   # four tiles per workgroup: 16 tiles per head
+    ([1000, 330, 64, 700] * 8, [1300, 330, 326, 700] * 8),        # four per workgroup, ragged: 16, 6, 1 and 11 tiles
 ])
 def test_prefill_hand_scheduled_kernel_two_tiles_per_workgroup(hip, tuning, n_qs, n_ks):
-    """Launches with many workgroups give every workgroup two query tiles of one head (the last and the
-    first, the second last and the second, ...): the second tile's first key tiles and its Q fragments are
-    fetched while the first tile finishes.  A key with a much larger score late in the visible range of a
+    """Launches with many workgroups give every workgroup two or four query tiles of one head (chosen from
+    both ends of the sequence so that all workgroups have equal work): the next tile's first key tiles and
+    its Q fragments are fetched while the current tile finishes.  A key with a much larger score late in the visible range of a
     row of the FIRST query tile (processed second) drives the accumulator rescale through that path too."""
     _, ops = hip
     H_q, H_kv, bs = 16, 2, 256

@@ -233,6 +233,8 @@ STATS: dict = {}
 # placement knobs (experiments): MFMAs of phase 2 that carry the maxima; spacing of the V reads in phase 1
 # (v_pk_fma_f32 / v_pk_add_f32 / v_dot2_f32_bf16 in the exp stream measured slower than the plain instructions
 # they replace; see the experiments notes of the profiles directory.)
+# timing-only early exits (nothing is stored): PF_EXIT=setup | fetched | prologue
+EXIT_AT = os.environ.get("PF_EXIT", "")
 # timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,lgkm
 ABLATE = set(filter(None, os.environ.get("PF_ABLATE", "").split(",")))
 
@@ -562,6 +564,9 @@ def gen_setup(o: Out):
     read_descriptor(o, S_ITEM)
     lane_consts(o)
     q_fetch(o, S_RW0, K(0, 0))
+    if EXIT_AT == "setup":
+        o.e("s_waitcnt vmcnt(0)")
+        o.e("s_branch .Lpf_end")
 
 
 def q_prescale(o: Out):
@@ -613,6 +618,8 @@ def gen_item_prologue(o: Out):
     o.e("s_waitcnt vmcnt(0)")
     q_prescale(o)
     o.e("s_barrier")
+    if EXIT_AT == "fetched":
+        o.e("s_branch .Lpf_end")
     o.e(f"s_cmp_eq_u32 s{S_NT}, 0")
     o.e("s_cbranch_scc1 .Lpf_fin")
     for ln in k_reads(0):
@@ -641,6 +648,8 @@ def gen_item_prologue(o: Out):
     o.e("s_waitcnt vmcnt(0)")
     o.e("s_barrier")
     o.e(f"s_mov_b32 s{S_J}, 1")
+    if EXIT_AT == "prologue":
+        o.e("s_branch .Lpf_end")
     o.e(f"s_cmp_le_u32 s{S_NT}, 1")
     o.e("s_cbranch_scc1 .Lpf_epi0")
 
