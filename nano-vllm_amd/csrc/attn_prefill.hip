@@ -24,6 +24,10 @@
 #include "nv_common.h"
 #include "attn_prefill_shared.h"
 
+#ifndef NV_PF_MAX_ITEMS
+#define NV_PF_MAX_ITEMS 4
+#endif
+
 namespace nv {
 
 // LDS image of a [64 keys][128 dims] bf16 tile: 8-row x 32-column subtiles of 512 bytes,
@@ -385,6 +389,8 @@ __global__ __launch_bounds__(256) void attn_prefill_merge_kernel(const PrefillPa
     }
 }
 
+constexpr int kMaxItemsPerWg = NV_PF_MAX_ITEMS;   // query tiles per workgroup of the hand-scheduled kernel (<= 8)
+
 static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 
 struct PrefillShape {
@@ -443,7 +449,7 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
         // workgroups per CU
         if (sh.nsplit == 1) {
             const int groups = sh.wg_per_pair / sh.n_qtiles;
-            for (int m = 4; m >= 2; m /= 2) {
+            for (int m = kMaxItemsPerWg; m >= 2; m /= 2) {
                 const int slots = (sh.n_qtiles + m - 1) / m;
                 if ((int64_t)sh.n_pairs * slots * groups >= 512) {
                     sh.items_per_wg = m;
