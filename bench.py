@@ -239,7 +239,40 @@ def _time_launches(fn, n_variants, iters, dev):
     return a.elapsed_time(b) / iters
 
 
-def prefill_records(dev, iters=10):
+def mfma_ceiling_record(dev, launches=5):
+    """bf16 MFMA rate this box sustains on v_mfma_f32_32x32x16_bf16 alone (tools/micro/mfma_ceiling.hip, one
+    wave per SIMD, register operands): the clock a chip holds under matrix load differs from box to box, so the
+    prefill records are priced against this measured ceiling as well as against the nominal peak.  None when
+    the probe library has not been built."""
+    import ctypes
+    path = os.path.join(ROOT, "tools", "micro", "libmfma_ceiling.so")
+    if not os.path.exists(path):
+        return None
+    dll = ctypes.CDLL(path)
+    dll.mfma_ceiling_flops.restype = ctypes.c_double
+    dll.mfma_ceiling_flops.argtypes = [ctypes.c_int, ctypes.c_int]
+    dll.mfma_ceiling_launch.restype = ctypes.c_int
+    dll.mfma_ceiling_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    blocks, iters = 1024, 4000
+    sink = torch.zeros(blocks * 256, dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    rates = {}
+    for name, rnd in (("random_operands", 1), ("constant_operands", 0)):
+        def launch(_):
+            rc = dll.mfma_ceiling_launch(sink.data_ptr(), blocks, iters, rnd, stream)
+            if rc != 0:
+                raise RuntimeError(f"mfma_ceiling_launch: hip error {rc}")
+        ms = _time_launches(launch, 1, launches, dev)
+        rates[name] = round(dll.mfma_ceiling_flops(blocks, iters) / (ms * 1e-3) / 1e12, 1)
+    # attention data toggles the datapath like the random operands do: that rate is the ceiling used
+    return {"achieved_tflops": rates["random_operands"], "achieved_tflops_constant_operands": rates["constant_operands"],
+            "nominal_peak": MFMA_PEAK_TFLOPS,
+            "kernel": "tools/micro/mfma_ceiling.hip: back-to-back independent v_mfma_f32_32x32x16_bf16 on register "
+                      "operands, 4 waves per workgroup, 1024 workgroups, no memory traffic"}
+
+
+def prefill_records(dev, iters=10, ceiling_tflops=None):
     """Prefill / chunked-prefill attention (bf16 MFMA kernel) on BASELINE config 3 shapes (Qwen3-8B attention:
     32 query / 8 kv heads x 128, block 256).  flops = 4 * D * H_q * visible (query, key) pairs."""
     from nanovllm_amd import _lib
@@ -285,6 +318,8 @@ def prefill_records(dev, iters=10):
         out.append({"workload": f"Qwen3-8B attention shapes (H {H_q}/{H_kv}, D {D}, block {bs}): {label}",
                     "launches": len(plans), "flops": flops, "ms": round(ms, 4), "achieved_tflops": round(tf, 1),
                     "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4)})
+        if ceiling_tflops:
+            out[-1]["frac_of_measured_mfma_ceiling"] = round(tf / ceiling_tflops, 4)
         del plans, kc, vc
         torch.cuda.empty_cache()
     return out
@@ -511,9 +546,10 @@ def main():
     torch.cuda.empty_cache()
     tp = None if args.no_tp else tp_bench(args, dev, rank, world, dist)
 
-    extra_prefill = extra_cfg = None
+    extra_prefill = extra_cfg = ceiling = None
     if rank == 0 and not args.no_prefill:
-        extra_prefill = prefill_records(dev)
+        ceiling = mfma_ceiling_record(dev)
+        extra_prefill = prefill_records(dev, ceiling_tflops=ceiling["achieved_tflops"] if ceiling else None)
     if rank == 0 and not args.no_configs:
         extra_cfg = decode_config_records(dev)
 
@@ -564,6 +600,8 @@ def main():
         }
         if extra_prefill is not None:
             out["prefill"] = extra_prefill
+            if ceiling is not None:
+                out["mfma_ceiling"] = ceiling
         if extra_cfg is not None:
             out["decode_by_config"] = extra_cfg
         if tp is not None:
