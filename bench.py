@@ -258,7 +258,7 @@ def mfma_ceiling_record(dev, launches=5):
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     rates = {}
-    for name, rnd in (("random_operands", 1), ("constant_operands", 0)):
+    for name, rnd in (("random_operands", 1), ("random_operands_16x16x32", 2), ("constant_operands", 0)):
         def launch(_):
             rc = dll.mfma_ceiling_launch(sink.data_ptr(), blocks, iters, rnd, stream)
             if rc != 0:
@@ -267,6 +267,7 @@ def mfma_ceiling_record(dev, launches=5):
         rates[name] = round(dll.mfma_ceiling_flops(blocks, iters) / (ms * 1e-3) / 1e12, 1)
     # attention data toggles the datapath like the random operands do: that rate is the ceiling used
     return {"achieved_tflops": rates["random_operands"], "achieved_tflops_constant_operands": rates["constant_operands"],
+            "achieved_tflops_16x16x32_random_operands": rates["random_operands_16x16x32"],
             "nominal_peak": MFMA_PEAK_TFLOPS,
             "kernel": "tools/micro/mfma_ceiling.hip: back-to-back independent v_mfma_f32_32x32x16_bf16 on register "
                       "operands, 4 waves per workgroup, 1024 workgroups, no memory traffic"}

@@ -47,6 +47,31 @@ __global__ __launch_bounds__(256) void mfma_ceiling_kernel(float* sink, int iter
     if (t == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = t;      // keeps the chains alive; never true in practice
 }
 
+// The other bf16 shape, 16x16x32 (same flops per cycle: 16 cycles per instruction), random operands.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ __launch_bounds__(256) void mfma_ceiling_16x16_kernel(float* sink, int iters) {
+    bf16x8 a, b, a2, b2;
+    for (int i = 0; i < 8; ++i) {
+        const unsigned id = (blockIdx.x * 256 + threadIdx.x) * 32 + i;
+        a[i] = (__bf16)pseudo_random(id);
+        b[i] = (__bf16)pseudo_random(id + 8);
+        a2[i] = (__bf16)pseudo_random(id + 16);
+        b2[i] = (__bf16)pseudo_random(id + 24);
+    }
+    f32x4 c[16] = {};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                c[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16((k & 1) ? a2 : a, (k & 2) ? b2 : b, c[k], 0, 0, 0);
+        }
+    }
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += c[k][0] + c[k][1] + c[k][2] + c[k][3];
+    if (t == 12345.678f) sink[blockIdx.x * 256 + threadIdx.x] = t;
+}
+
 extern "C" {
 // MFMAs per wave per launch = 32 * iters; flops per MFMA = 2 * 32 * 32 * 16.
 __attribute__((visibility("default"))) double mfma_ceiling_flops(int blocks, int iters) {
@@ -55,7 +80,9 @@ __attribute__((visibility("default"))) double mfma_ceiling_flops(int blocks, int
 // sink: device buffer of blocks * 256 floats (never written in practice).  Returns the hipError_t of the launch.
 __attribute__((visibility("default"))) int mfma_ceiling_launch(void* sink, int blocks, int iters, int random_operands, void* stream) {
     if (sink == nullptr || blocks <= 0 || iters <= 0) return -1;
-    if (random_operands)
+    if (random_operands == 2)     // 64 MFMAs of half the flops per iteration: the same flops per launch
+        hipLaunchKernelGGL(mfma_ceiling_16x16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters);
+    else if (random_operands)
         hipLaunchKernelGGL(mfma_ceiling_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
     else
         hipLaunchKernelGGL(mfma_ceiling_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)sink, iters, 1.0f);
