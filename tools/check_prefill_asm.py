@@ -13,7 +13,8 @@ checked on its OUTPUT:
   4. Short fixed distances: the result of a transcendental instruction is not read by the next instruction; a
      register written by a vector instruction is read by v_permlane32_swap at the earliest two slots later and
      by v_readfirstlane one slot later; a scalar register written by a vector instruction (v_readfirstlane,
-     v_cmp) is used by a memory instruction as address base at the earliest five slots later.
+     v_cmp) is used by a memory instruction as address base at the earliest five slots later; an MFMA reads an
+     operand register written by a vector (non-MFMA) instruction at the earliest two slots later.
 
 The walk is linear over the text.  A label that is only reached by branches starts from the union of the states
 at the branches to it; a label reached by falling through joins that union with the fall-through state.
@@ -129,6 +130,10 @@ def check_short_distances(lines: list) -> list:
             errors.append(f"line {i}: '{ln}' reads the result of the transcendental instruction right in front of it")
         if op.startswith("v_permlane") and written_within(2, src):
             errors.append(f"line {i}: '{ln}' reads a register a vector instruction wrote less than two slots before")
+        if kind == "mfma":
+            w = written_within(2, src | dst)
+            if w and not w.startswith("v_mfma"):
+                errors.append(f"line {i}: '{ln}' reads an operand a vector instruction ({w}) wrote less than two slots before")
         if op.startswith("v_readfirstlane") and written_within(1, src):
             errors.append(f"line {i}: '{ln}' reads a register the instruction in front of it wrote")
         if kind in ("vm_load", "vm_other"):

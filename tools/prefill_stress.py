@@ -65,15 +65,44 @@ def run(rounds=30, H_q=16, H_kv=8, verbose=True):
                 outs.append(big)
             _lib.set_tuning()
             torch.cuda.synchronize()
+            other_path = os.environ.get("NV_STRESS_OTHER_LIB")
+            if other_path:
+                # development aid: the same launch through another build of the library, compared bit for bit
+                import ctypes
+                from tools.pf_two_libs import bind
+                other = bind(other_path)
+                t = _lib.Tuning(**{**_lib.Tuning.DEFAULTS, "prefill_kernel": 1})
+                assert other.nv_set_tuning(ctypes.byref(t)) == 0
+                big = torch.full((guard + T + lead + guard, H_q, D), float("nan"), dtype=torch.bfloat16, device=dev)
+                o = big[guard:guard + T + lead]
+                ws = torch.empty(max(16, other.nv_attn_prefill_workspace_bytes(B, T, max(n_qs), max(n_ks), H_q, H_kv, D)),
+                                 dtype=torch.uint8, device=dev)
+                rc = other.nv_attn_prefill_varlen(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), cu_q.data_ptr(),
+                                                  cu_k.data_ptr(), bt.data_ptr(), B, width, max(n_qs), max(n_ks), H_q, H_kv, D,
+                                                  nb, bs, D ** -0.5, q.stride(0), o.stride(0), 0, T + lead, ws.data_ptr(),
+                                                  ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                ne = outs[1][guard + lead:guard + lead + T].view(torch.int16) != big[guard + lead:guard + lead + T].view(torch.int16)
+                if ne.any():
+                    i = ne.nonzero()[0].tolist()
+                    print(f"round {rnd} shape {n_qs}: builds differ in {int(ne.sum())} elements, first {i}: "
+                          f"{outs[1][guard + lead:][tuple(i)].item()} vs {big[guard + lead:][tuple(i)].item()} "
+                          f"(kernel 0: {outs[0][guard + lead:][tuple(i)].item()})", flush=True)
             launches += 1
             ref, new = outs
             canary_ok = bool(torch.isnan(new[:guard + lead]).all() and torch.isnan(new[guard + lead + T:]).all())
             body_r, body_n = ref[guard + lead:guard + lead + T].float(), new[guard + lead:guard + lead + T].float()
             err = (body_r - body_n).abs().max().item()
             nan_rows = int(torch.isnan(body_n).any(dim=(1, 2)).sum())
-            if not canary_ok or not (err <= 2e-2) or nan_rows:
+            # 2e-2 absolute, or one bf16 unit in the last place where that is larger (|value| >= 4: rows that see
+            # one or two keys reproduce V values of that size, and the two kernels round p differently)
+            over = (body_r - body_n).abs() > torch.clamp(body_r.abs() * 2.0 ** -7, min=2e-2)
+            if not canary_ok or bool(over.any()) or nan_rows:
                 bad += 1
-                rows = (((body_r - body_n).abs() > 2e-2) | torch.isnan(body_n)).any(dim=(1, 2)).nonzero().flatten().tolist()
+                rows = (over | torch.isnan(body_n)).any(dim=(1, 2)).nonzero().flatten().tolist()
+                w = (body_r - body_n).abs().flatten().argmax().item()
+                print(f"  largest difference: kernel 0 {body_r.flatten()[w].item()} kernel 1 {body_n.flatten()[w].item()}")
                 print(f"round {rnd} shape {n_qs}: canaries {'ok' if canary_ok else 'TOUCHED'} max diff {err:.4g} "
                       f"nan rows {nan_rows} bad rows {rows[:12]} (total {len(rows)})", flush=True)
         if verbose and rnd % 10 == 9:
