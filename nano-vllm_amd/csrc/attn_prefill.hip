@@ -491,6 +491,7 @@ extern "C" int64_t nv_attn_prefill_workspace_bytes(int B, int total_q, int max_s
         return 0;
     const PrefillShape sh = prefill_shape(B, H_q, H_kv, max_seqlen_q, max_seqlen_k);
     if (sh.nsplit == 1) return 16;
+    if (sh.hand_scheduled) return prefill_asm_state_bytes(sh.grid_base, sh.nsplit);
     return (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
 }
 
@@ -553,7 +554,9 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.grid_base = (int)sh.grid_base;
     p.pair_items = sh.items_per_wg;
     if (sh.nsplit > 1) {
-        const int64_t need = (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
+        const int64_t need = sh.hand_scheduled
+                                 ? prefill_asm_state_bytes(sh.grid_base, sh.nsplit)
+                                 : (int64_t)total_q * H_q * sh.nsplit * kPartStride * (int64_t)sizeof(float);
         NV_REQUIRE(workspace && workspace_bytes >= need, NV_ERR_WORKSPACE,
                    "nv_attn_prefill_varlen: workspace %lld bytes < required %lld",
                    (long long)workspace_bytes, (long long)need);
@@ -570,6 +573,10 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
         rc = check_launch("nv_attn_prefill_varlen");
     }
     if (rc != NV_OK || sh.nsplit == 1) return rc;
+    if (sh.hand_scheduled) {
+        launch_prefill_asm_merge(p, st);
+        return check_launch("nv_attn_prefill_varlen(merge)");
+    }
     hipLaunchKernelGGL(attn_prefill_merge_kernel,
                        dim3((unsigned)(((int64_t)max_seqlen_q * H_q + 7) / 8), (unsigned)B),
                        dim3(256), 0, st, p);

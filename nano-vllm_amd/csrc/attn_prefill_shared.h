@@ -10,6 +10,10 @@ constexpr float kRunInit = -1.0e30f;        // finite initial running max (keeps
 constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 between rescales
 
 constexpr int kPartStride = kHeadDim + 4;    // fp32 per partial state: 128 acc + m + l + 2 pad
+// hand-scheduled kernel: one unit per (wave, key range) = its 64 rows in register order
+// [qb 2][d 4][g 4][lane 64][4 floats] followed by [qb 2][lane 64][m, l]
+constexpr int kImageAcc = 2 * 4 * 4 * 64 * 16;
+constexpr int kImageUnit = kImageAcc + 2 * 64 * 8;
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -33,7 +37,8 @@ struct PrefillParams {
     float scale_log2;
     int skip_single;
     // key-range splitting (launches with too few workgroups for the chip)
-    float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states
+    float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states (hand-scheduled kernel:
+                          // [grid_base * 4 waves, nsplit] units of kImageUnit bytes)
     int nsplit;           // 1: results are written directly
     int tiles_per_split;  // 64-key tiles per split
     int grid_base;        // workgroups per split (multiple of 8)
@@ -42,6 +47,8 @@ struct PrefillParams {
 
 // hand-scheduled kernel for large launches (attn_prefill_asm.hip): one wave per SIMD, 64 query rows per wave
 void launch_prefill_asm(const PrefillParams& p, int64_t grid, hipStream_t st);
+void launch_prefill_asm_merge(const PrefillParams& p, hipStream_t st);   // combines its key-range states
+int64_t prefill_asm_state_bytes(int64_t grid_base, int nsplit);
 int prefill_asm_max_tiles();
 
 }  // namespace nv

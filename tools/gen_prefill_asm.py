@@ -67,7 +67,7 @@ S_NT, S_J, S_C, S_TAIL, S_MASKFROM, S_MASKED, S_RESC, S_PIECE, S_STG, S_TBL = 40
 S_T0 = 50                      # s50..s57 temporaries
 S_CMP = 60                     # s[60:67] compare results
 S_DESC, S_NITEMS, S_ITEM = 68, 69, 70      # LDS address of the wave's item descriptors, item count, current item
-S_MODE = 71                    # 0: bf16 output rows; 1: unnormalised fp32 states of a key range (128 + m + l per row)
+S_MODE = 71                    # 0: bf16 output rows; 1: the unnormalised fp32 state of a key range (partial_state_store)
 S_QSEQ, S_OSEQ = 72, 74        # 64-bit: row 0 of this wave's query head in q / in o (of the sequence)
 S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
 S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
@@ -802,22 +802,21 @@ def gen_epilogue(o: Out, qbuf):
 
 
 def partial_state_store():
-    """Key-range split: the wave's rows leave as unnormalised fp32 states [128 accumulators, m, l] (row stride
-    s_ostr bytes), 16 bytes per lane and store (lane (r, h) holds dims 32 d + 8 g + 4 h .. + 3 of row 32 qb + r).
-    Out of line; v[0:67] are free here."""
+    """Key-range split: the wave's rows leave as an unnormalised fp32 state in the order the registers hold it,
+    one 33,792-byte unit per (wave, key range) at s[S_OSEQ:S_OSEQ+1]:
+        [qb 2][d 4][g 4][lane 64][4 floats]   lane (r, h) holds dims 32 d + 8 g + 4 h .. + 3 of row 32 qb + r
+        [qb 2][lane 64][m, l]                 at byte 32768 (the same pair in both lanes of a row)
+    so every store instruction writes 1 KiB (512 B) of consecutive memory; attn_prefill_merge_image_kernel reads
+    the units back.  All 64 rows are written (rows behind the end of the sequence repeat its last row; the merge
+    does not store them).  Out of line; v[0:67] are free here."""
     b = [".Lpf_fin_part:"]
-    b += [f"  s_mul_i32 s{S_T0}, s{S_RW0}, s{S_OSTR}", f"  s_mul_hi_u32 s{S_T0 + 1}, s{S_RW0}, s{S_OSTR}",
-          f"  s_add_u32 s{S_T0 + 2}, s{S_OSEQ}, s{S_T0}", f"  s_addc_u32 s{S_T0 + 3}, s{S_OSEQ + 1}, s{S_T0 + 1}",
+    b += [f"  s_mov_b64 s[{S_T0 + 2}:{S_T0 + 3}], s[{S_OSEQ}:{S_OSEQ + 1}]",
           f"  v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0", f"  v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}",
-          f"  v_and_b32 v{T[4]}, 31, v{T[0]}", f"  v_lshrrev_b32 v{T[5]}, 5, v{T[0]}", f"  v_lshlrev_b32 v{T[5]}, 4, v{T[5]}"]
+          f"  v_lshlrev_b32 v{T[3]}, 4, v{T[0]}",                                       # 16 bytes per lane
+          f"  v_lshlrev_b32 v{T[2]}, 3, v{T[0]}", f"  v_add_u32 v{T[2]}, 0x8000, v{T[2]}"]  # (m, l) pairs behind the image
     k = 0
     for qb in range(2):
-        b += [f"  v_add_u32 v{T[1]}, {32 * qb}, v{T[4]}",                              # row of the lane
-              f"  v_mul_u32_u24 v{T[2]}, v{T[1]}, s{S_OSTR}",                          # its byte offset
-              f"  v_add_u32 v{T[3]}, v{T[2]}, v{T[5]}",                                # + 16 h
-              f"  v_sub_f32 v{64 + 2 * qb}, 0, v{NMB(qb)}", f"  v_mov_b32 v{65 + 2 * qb}, v{L[qb]}",
-              f"  v_cmp_gt_i32 vcc, s{S_ROWS}, v{T[1]}",
-              f"  s_and_saveexec_b64 s[{S_SAVE}:{S_SAVE + 1}], vcc"]
+        b += [f"  v_sub_f32 v{64 + 2 * qb}, 0, v{NMB(qb)}", f"  v_mov_b32 v{65 + 2 * qb}, v{L[qb]}"]
         for d in range(4):
             for g in range(4):
                 r0 = 4 * (k % 16)
@@ -825,9 +824,9 @@ def partial_state_store():
                 for i in range(4):
                     b.append(f"  v_accvgpr_read_b32 v{r0 + i}, a{O(qb, d, 4 * g + i)}")
                 b.append("  s_nop 0")
-                b.append(f"  global_store_dwordx4 v{T[3]}, v[{r0}:{r0 + 3}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{d * 128 + g * 32}")
-        b.append(f"  global_store_dwordx2 v{T[2]}, v[{64 + 2 * qb}:{65 + 2 * qb}], s[{S_T0 + 2}:{S_T0 + 3}] offset:512")
-        b.append(f"  s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
+                b.append(f"  global_store_dwordx4 v{T[3]}, v[{r0}:{r0 + 3}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{g * 1024}")
+            b.append(f"  v_add_u32 v{T[3]}, 0x1000, v{T[3]}")
+        b.append(f"  global_store_dwordx2 v{T[2]}, v[{64 + 2 * qb}:{65 + 2 * qb}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{qb * 512}")
     b.append("  s_branch .Lpf_fin_next")
     _ool.append(b)
 
