@@ -273,6 +273,26 @@ def test_attention_golden_cases(hip, golden):
             _attn_check(_run_attention(ops, p, mode), ref, f"{name}/{mode}")
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_chunked_prefill_reproduces_reference_pinned_full_prefill_rows(hip, golden, tuning, kernel):
+    """The chunk-invariance anchor of tests/test_oracle_golden.py on the GPU, both prefill kernels: a chunk
+    of rows lo..hi-1 over hi cached keys must reproduce those rows of the full-prefill output, and the
+    stored full-prefill outputs are the reference's own dense helper's (nanovllm/layers/attention.py:273-335)."""
+    from test_oracle_golden import FULL_PREFILL_CASES, chunk_problems
+    _, ops = hip
+    g = golden("g4_attention.npz")
+    tuning(prefill_kernel=kernel)
+    chunks = 0
+    for name in FULL_PREFILL_CASES:
+        want = torch.from_numpy(g[f"{name}_out"])
+        kc, vc = bf16(g[f"{name}_k_cache"]).to(DEV), bf16(g[f"{name}_v_cache"]).to(DEV)
+        for p, rows in chunk_problems(g, name):
+            pd = to_dev(dict(p, k_cache=kc, v_cache=vc, scale=float(g[f"{name}_scale"])))
+            _attn_check(_run_attention(ops, pd, "prefill"), want[rows], f"{name} rows {rows} kernel {kernel}")
+            chunks += 1
+    assert chunks >= 20
+
+
 @pytest.mark.parametrize("H_q,H_kv", [(16, 8), (32, 8), (64, 8), (8, 8), (8, 1)])
 @pytest.mark.parametrize("bs", [256, 16])
 def test_decode_ragged_against_oracle(hip, H_q, H_kv, bs):

@@ -87,6 +87,47 @@ def test_attention_oracle_equals_stored_reference_outputs(golden):
             "bs256_decode_g4", "bs256_decode_g8"} <= names
 
 
+FULL_PREFILL_CASES = ["full_prefill_g2", "bs256_full_prefill_g2", "bs256_full_prefill_g4", "bs256_full_prefill_g8"]
+
+
+def chunk_problems(g, name):
+    """Every full-prefill sequence of fixture case `name` cut into chunks (uneven, one of a single row):
+    yields (chunk problem as tensors, rows of the case's stored output the chunk must reproduce)."""
+    cu_q = g[f"{name}_cu_q"]
+    q = bf16(g[f"{name}_q"])
+    bt = torch.from_numpy(g[f"{name}_block_tables"])
+    for b in range(len(cu_q) - 1):
+        n = int(cu_q[b + 1] - cu_q[b])
+        if n < 4:
+            continue
+        cuts = sorted({0, n // 3, n // 3 + 1, (2 * n) // 3, n})
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            rows = slice(int(cu_q[b]) + lo, int(cu_q[b]) + hi)
+            yield dict(q=q[rows], cu_q=torch.tensor([0, hi - lo], dtype=torch.int32),
+                       cu_k=torch.tensor([0, hi], dtype=torch.int32), block_tables=bt[b:b + 1].contiguous(),
+                       max_q=hi - lo, max_k=hi), rows
+
+
+def test_chunked_prefill_reproduces_reference_pinned_full_prefill_rows(golden):
+    """Anchor for the bottom-right causal alignment that needs no flash-attn: rows lo..hi-1 of a prompt
+    attend to keys 0..row whether the prompt is prefilled at once or the rows arrive as a later chunk
+    (n_q = hi - lo queries over n_k = hi cached keys), so a chunk must reproduce those rows of the
+    full-prefill output.  The full-prefill outputs stored in g4 are the reference's own dense helper's
+    (nanovllm/layers/attention.py:273-335, valid for n_q == n_k); a top-left aligned mask (that helper's
+    `tril`, wrong for chunks) would fail here on every chunk with lo > 0."""
+    g = golden("g4_attention.npz")
+    chunks = 0
+    for name in FULL_PREFILL_CASES:
+        assert g[f"{name}_ref_pinned"].all()
+        want = torch.from_numpy(g[f"{name}_out"])
+        kc, vc, scale = bf16(g[f"{name}_k_cache"]), bf16(g[f"{name}_v_cache"]), float(g[f"{name}_scale"])
+        for p, rows in chunk_problems(g, name):
+            o = ref_attention.paged_attention_ref(p["q"], kc, vc, p["cu_q"], p["cu_k"], p["block_tables"], scale)
+            assert (o - want[rows]).abs().max().item() <= 1e-5, (name, rows)
+            chunks += 1
+    assert chunks >= 20
+
+
 def test_attention_bottom_right_mask_small_case():
     """n_q=2, n_k=3: query 0 sees keys 0..1, query 1 sees keys 0..2; and decode == no mask."""
     D = 128

@@ -47,6 +47,9 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     bs, D = 256, 128
     for name in args.cases.split(","):
+        if name.startswith("chunk_"):                 # chunk_<queries>x<keys>: one sequence, 32 / 8 heads
+            nq, nk = (int(x) for x in name[6:].split("x"))
+            CASES[name] = ([nq], [nk], 32, 8)
         n_qs, n_ks, H_q, H_kv = CASES[name]
         B = len(n_qs)
         blocks = [math.ceil(n / bs) for n in n_ks]
