@@ -235,6 +235,9 @@ STATS: dict = {}
 # they replace; see the experiments notes of the profiles directory.)
 # timing-only early exits (nothing is stored): PF_EXIT=setup | fetched | prologue
 EXIT_AT = os.environ.get("PF_EXIT", "")
+# timing-only (wrong results): PF_SKIP=finish drops the output normalisation / transposition / stores of an
+# item, PF_SKIP=epi the last tile's softmax and products (the next item's prefetch stays)
+SKIP = set(filter(None, os.environ.get("PF_SKIP", "").split(",")))
 # timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,lgkm
 ABLATE = set(filter(None, os.environ.get("PF_ABLATE", "").split(",")))
 
@@ -761,10 +764,13 @@ def gen_epilogue(o: Out, qbuf):
     for ln in v_reads(qbuf, [0, 1]):
         o.e(ln)
     for x in plain(exps_p1(qbuf)):
-        o.e(x)
+        if "epi" not in SKIP:
+            o.e(x)
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_nop 1")
     pv = pv_mfmas()
+    if "epi" in SKIP:
+        pv = ["s_nop 0"] * 32
     for m in pv[0:9]:
         o.e(m)
     for ln in v_reads(qbuf, [2]):
@@ -833,6 +839,8 @@ def partial_state_store():
 
 def gen_finish(o: Out):
     o.label(".Lpf_fin")
+    if "finish" in SKIP:
+        o.e("s_branch .Lpf_fin_next")
     o.c("denominators: add the share of the lane that holds the other half of each row; 1 / l (0 for rows without keys)")
     o.e("s_nop 15")
     o.e("s_nop 15")
