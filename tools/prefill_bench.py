@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", default="")
+    ap.add_argument("--split", type=int, default=0, help="nv_tuning.prefill_split (0 = the launch plan's choice)")
     ap.add_argument("--kernels", default="auto", help="comma list of auto,0,1 (nv_tuning.prefill_kernel: 0 compiler-scheduled, 1 hand-scheduled)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -85,7 +86,8 @@ def main():
         ts = {k: [] for k in kernels}
         for rnd in range(args.rounds + 1):
             for k in kernels:                      # interleaved rounds in one process
-                t = _lib.Tuning(**{**_lib.Tuning.DEFAULTS, **({} if k == "auto" else {"prefill_kernel": int(k)})})
+                t = _lib.Tuning(**{**_lib.Tuning.DEFAULTS, **({} if k == "auto" else {"prefill_kernel": int(k)}),
+                                   "prefill_split": args.split})
                 assert dll.nv_set_tuning(t) == 0
                 need = dll.nv_attn_prefill_workspace_bytes(B, T, max(n_qs), max(n_ks), H_q, H_kv, D)
                 if need > ws.numel():
