@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", default="")
+    ap.add_argument("--share-kv", action="store_true", help="every sequence uses the first sequence's blocks (small K/V footprint)")
     ap.add_argument("--split", type=int, default=0, help="nv_tuning.prefill_split (0 = the launch plan's choice)")
     ap.add_argument("--kernels", default="auto", help="comma list of auto,0,1 (nv_tuning.prefill_kernel: 0 compiler-scheduled, 1 hand-scheduled)")
     args = ap.parse_args()
@@ -48,6 +49,9 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     bs, D = 256, 128
     for name in args.cases.split(","):
+        if name.startswith("full_"):                  # full_<sequences>x<tokens>: whole-prompt prefill, 32 / 8 heads
+            nb_, nt_ = (int(x) for x in name[5:].split("x"))
+            CASES[name] = ([nt_] * nb_, [nt_] * nb_, 32, 8)
         if name.startswith("chunk_"):                 # chunk_<queries>x<keys>: one sequence, 32 / 8 heads
             nq, nk = (int(x) for x in name[6:].split("x"))
             CASES[name] = ([nq], [nk], 32, 8)
@@ -62,6 +66,9 @@ def main():
         for nb in blocks:
             tables.append(perm[nxt:nxt + nb] + [-1] * (width - nb))
             nxt += nb
+        if args.share_kv:
+            tables = [tables[0][:len(t)] + [-1] * (len(t) - len(tables[0])) if blocks[i] <= blocks[0] else t
+                      for i, t in enumerate(tables)]
         bt = torch.tensor(tables, dtype=torch.int32, device=dev)
         cu_q = torch.tensor([0] + torch.tensor(n_qs).cumsum(0).tolist(), dtype=torch.int32, device=dev)
         cu_k = torch.tensor([0] + torch.tensor(n_ks).cumsum(0).tolist(), dtype=torch.int32, device=dev)
