@@ -423,7 +423,8 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     // launches that fill the chip with 64-row waves AND have long key ranges (nv_tuning.prefill_kernel
     // forces either kernel).  Its fixed cost per workgroup is about 12 us against 8 us here, its cost per
     // key tile lower: measured with 4096 workgroups it is 36 % slower at 1 tile per workgroup, 15 % at 4,
-    // equal at 8 and 9 - 13 % faster from 16 tiles on.
+    // equal at 8 and 9 - 13 % faster from 16 tiles on; on whole-prompt prefills (several query tiles per
+    // workgroup) it is 5 % faster at 512 tokens (8 tiles), 13 % at 1024, 18 % at 2048.
     prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 64);
     const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
     // with fewer workgroups than CUs it splits the key range like the other kernel does (one workgroup per
@@ -440,7 +441,7 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     }
     const bool asm_fills_chip = big_wgs >= 256 || (ns_asm >= 2 && big_wgs * ns_asm >= 128);
     sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1
-                                               : (asm_fills_chip && tiles >= (big_wgs >= 256 ? 16 : 24));
+                                               : (asm_fills_chip && tiles >= (big_wgs >= 256 ? 8 : 24));
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
     sh.items_per_wg = 1;
     if (sh.hand_scheduled) {
