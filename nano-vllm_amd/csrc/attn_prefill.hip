@@ -566,7 +566,8 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
                    (long long)workspace_bytes, (long long)need);
     }
     const int64_t grid = sh.grid_base * sh.nsplit;
-    NV_REQUIRE(grid < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_prefill_varlen: launch too large");
+    NV_REQUIRE(grid < (1LL << 31) && (sh.nsplit == 1 || sh.grid_base < (1LL << 27)), NV_ERR_UNSUPPORTED,
+               "nv_attn_prefill_varlen: launch too large");   // (the merge of a split launch has 8 workgroups per workgroup)
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (sh.hand_scheduled) {
