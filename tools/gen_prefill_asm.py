@@ -238,7 +238,7 @@ EXIT_AT = os.environ.get("PF_EXIT", "")
 # timing-only (wrong results): PF_SKIP=finish drops the output normalisation / transposition / stores of an
 # item, PF_SKIP=epi the last tile's softmax and products (the next item's prefetch stays)
 SKIP = set(filter(None, os.environ.get("PF_SKIP", "").split(",")))
-# timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,lgkm
+# timing-only ablations (wrong results by construction): PF_ABLATE=dma,barrier,exp,max,vread,kread,mfma,vmwait
 ABLATE = set(filter(None, os.environ.get("PF_ABLATE", "").split(",")))
 
 
@@ -258,6 +258,8 @@ def ablated(txt: str) -> bool:
         return True
     if "mfma" in ABLATE and op.startswith("v_mfma"):
         return True
+    if "vmwait" in ABLATE and txt.startswith("s_waitcnt vmcnt"):
+        return True          # (data may be read before it has landed: timing only)
     if op.startswith("s_cbranch") and (".Lpf_slow" in txt or ".Lpf_resc" in txt):
         return True          # every timing build skips the data-dependent side paths
     return False
