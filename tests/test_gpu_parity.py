@@ -590,13 +590,15 @@ def test_prefill_key_range_split_long_chunk(hip, tuning, kernel):
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("nsplit", [2, 3, 7])
-def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit, kernel):
-    """Forced split counts on a ragged mixed batch, both kernels: splits that lie wholly above a row block's
-    diagonal are empty, sequences with one query stay with the decode kernel."""
+@pytest.mark.parametrize("nsplit,H_q,H_kv", [(2, 16, 8), (3, 16, 8), (7, 16, 8), (3, 4, 4), (2, 16, 4), (3, 16, 2), (2, 12, 4)])
+def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit, H_q, H_kv, kernel):
+    """Forced split counts on a ragged mixed batch, both kernels, head groups of 1, 2, 3, 4 and 8 query heads per
+    kv head (a workgroup of the hand-scheduled kernel then holds 4, 2 or 1 row blocks of 64 per head, and its
+    merge kernel must find the same rows): splits that lie wholly above a row block's diagonal are empty,
+    sequences with one query stay with the decode kernel."""
     _, ops = hip
     n_qs, n_ks = [1, 70, 300, 5, 129], [40, 70, 700, 261, 1000]
-    p = make_paged_problem(31, n_qs, n_ks, 16, 8, 256, 12)
+    p = make_paged_problem(31, n_qs, n_ks, H_q, H_kv, 256, 12)
     ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
                                             p["block_tables"], p["scale"])
     pd = to_dev(p)
