@@ -545,14 +545,24 @@ def main():
     del plan
     w.kv_cache = None
     torch.cuda.empty_cache()
-    tp = None if args.no_tp else tp_bench(args, dev, rank, world, dist)
+    # The records below are additions to the line: a failure in one of them is reported in its place and
+    # never costs the line itself (an exception raised from the same arguments is raised on every rank alike,
+    # so no rank is left waiting in a collective).
+    def guarded(fn, *a, **kw):
+        try:
+            return fn(*a, **kw)
+        except Exception as e:      # noqa: BLE001
+            return {"error": f"{type(e).__name__}: {e}"}
+
+    tp = None if args.no_tp else guarded(tp_bench, args, dev, rank, world, dist)
 
     extra_prefill = extra_cfg = ceiling = None
     if rank == 0 and not args.no_prefill:
-        ceiling = mfma_ceiling_record(dev)
-        extra_prefill = prefill_records(dev, ceiling_tflops=ceiling["achieved_tflops"] if ceiling else None)
+        ceiling = guarded(mfma_ceiling_record, dev)
+        ceil_tf = ceiling.get("achieved_tflops") if isinstance(ceiling, dict) else None
+        extra_prefill = guarded(prefill_records, dev, ceiling_tflops=ceil_tf)
     if rank == 0 and not args.no_configs:
-        extra_cfg = decode_config_records(dev)
+        extra_cfg = guarded(decode_config_records, dev)
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be
@@ -616,8 +626,9 @@ def main():
             from tools.e2e_bench import run as e2e_run
             del w
             torch.cuda.empty_cache()
-            e = e2e_run(device=str(dev))
-            out["output_tok_per_s"] = round(e["output_tok_per_s"], 1)
+            e = guarded(e2e_run, device=str(dev))
+            if "error" not in e:
+                out["output_tok_per_s"] = round(e["output_tok_per_s"], 1)
             out["e2e"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()}
         print(json.dumps(out), flush=True)
         out = None
