@@ -39,17 +39,27 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* __restrict__ 
     const uint4* xr = x + (active ? row : 0) * x_stride_vec;
     const uint4* rr = ADD ? res + (active ? row : 0) * (int64_t)cols_vec : nullptr;
 
+    // Every load of the row is issued before the first use: x, the residual and the weights arrive in one
+    // round trip (at decode sizes the kernel is a chain of memory latencies, not a stream).
     float f[MAXV][8];
+    uint4 wv[MAXV], xv[MAXV], rv[MAXV];
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = first + i * step;
         if (active && c < cols_vec) {
-            const uint4 xv = xr[c];
-            const uint32_t xu[4] = {xv.x, xv.y, xv.z, xv.w};
+            xv[i] = xr[c];
+            if (ADD) rv[i] = rr[c];
+            wv[i] = w[c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = first + i * step;
+        if (active && c < cols_vec) {
+            const uint32_t xu[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
             if (ADD) {
-                const uint4 rv = rr[c];
-                const uint32_t ru[4] = {rv.x, rv.y, rv.z, rv.w};
+                const uint32_t ru[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
                 uint32_t nu[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -80,8 +90,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const uint4* __restrict__ 
     for (int i = 0; i < MAXV; ++i) {
         const int c = first + i * step;
         if (active && c < cols_vec) {
-            const uint4 wv = w[c];
-            const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+            const uint32_t wu[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -124,12 +133,11 @@ __device__ __forceinline__ float group8_sum(float x) {
 }
 
 template <bool NORM>
-__device__ __forceinline__ void head_norm_rope(const uint4* __restrict__ src,  // head base, 16 vec
-                                               const uint4* __restrict__ wgt,  // [16 vec] or null
-                                               const float4* __restrict__ cs,  // cos|sin row, 32 vec
-                                               int c, float eps, uint4& out1, uint4& out2) {
-    const uint4 a = src[c];
-    const uint4 b = src[8 + c];
+__device__ __forceinline__ void head_norm_rope(const uint4 a, const uint4 b,      // the head's x1 / x2 pieces
+                                               const uint4 wa, const uint4 wb,    // norm weights (NORM only)
+                                               const float4 c0, const float4 c1,  // cos[8c .. 8c+7]
+                                               const float4 s0, const float4 s1,  // sin[8c .. 8c+7]
+                                               float eps, uint4& out1, uint4& out2) {
     const uint32_t au[4] = {a.x, a.y, a.z, a.w};
     const uint32_t bu[4] = {b.x, b.y, b.z, b.w};
     float x1[8], x2[8];
@@ -146,8 +154,6 @@ __device__ __forceinline__ void head_norm_rope(const uint4* __restrict__ src,  /
         for (int j = 0; j < 8; ++j) ss += x1[j] * x1[j] + x2[j] * x2[j];
         ss = group8_sum(ss);
         const float r = rsqrtf(ss * (1.0f / 128.0f) + eps);
-        const uint4 wa = wgt[c];
-        const uint4 wb = wgt[8 + c];
         const uint32_t wau[4] = {wa.x, wa.y, wa.z, wa.w};
         const uint32_t wbu[4] = {wb.x, wb.y, wb.z, wb.w};
 #pragma unroll
@@ -159,8 +165,6 @@ __device__ __forceinline__ void head_norm_rope(const uint4* __restrict__ src,  /
             x2[2 * j + 1] = round_bf16(x2[2 * j + 1] * r * bf16_hi(wbu[j]));
         }
     }
-    const float4 c0 = cs[2 * c], c1 = cs[2 * c + 1];            // cos[8c .. 8c+7]
-    const float4 s0 = cs[16 + 2 * c], s1 = cs[16 + 2 * c + 1];  // sin[8c .. 8c+7]
     const float co[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     const float si[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     uint32_t o1[4], o2[4];
@@ -182,6 +186,10 @@ __device__ __forceinline__ void head_norm_rope(const uint4* __restrict__ src,  /
     out2 = make_uint4(o2[0], o2[1], o2[2], o2[3]);
 }
 
+// At decode sizes (a few hundred tokens) this kernel is a chain of memory latencies, so everything that
+// does not depend on the token's position is fetched first and in one go -- the first 32 heads, both norm
+// weights, the token's V row -- and only the cos / sin row waits for positions[t]; later passes (more than
+// 32 heads) fetch their heads one pass ahead.
 template <bool NORM>
 __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     const uint4* __restrict__ q, const uint4* __restrict__ k, const uint4* __restrict__ v,
@@ -191,29 +199,62 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
     uint4* __restrict__ k_out, int H_q, int H_kv, int64_t max_pos, float eps, int64_t num_slots,
     int64_t q_stride_vec, int64_t k_stride_vec, int64_t v_stride_vec) {
     const int t = blockIdx.x;
+    const int c = threadIdx.x & 7;
+    const int group = threadIdx.x >> 3;  // 32 head-groups per pass
+    const int n_heads = H_q + H_kv;
+    const uint4* qt = q + (int64_t)t * q_stride_vec;
+    const uint4* kt = k + (int64_t)t * k_stride_vec;
+    // Every lane of a wave runs the same trip count so the DPP reductions see valid
+    // neighbours; lanes whose head is out of range work on head 0 and discard.
+    auto head_src = [&](int hh) {
+        const int h = hh < n_heads ? hh : 0;
+        return h < H_q ? qt + (int64_t)h * 16 : kt + (int64_t)(h - H_q) * 16;
+    };
+    const uint4* src = head_src(group);
+    uint4 a = src[c], b = src[8 + c];
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint4 qwa = zero, qwb = zero, kwa = zero, kwb = zero;
+    if (NORM) {
+        qwa = q_w[c];
+        qwb = q_w[8 + c];
+        kwa = k_w[c];
+        kwb = k_w[8 + c];
+    }
+    const int v_vecs = H_kv * 16;
+    uint4 v0 = zero;
+    if (v && (int)threadIdx.x < v_vecs) v0 = v[(int64_t)t * v_stride_vec + threadIdx.x];
+
     int64_t pos = positions[t];
     pos = pos < 0 ? 0 : (pos >= max_pos ? max_pos - 1 : pos);
     const float4* cs = cos_sin + pos * 32;  // 128 fp32 per position
+    const float4 c0 = cs[2 * c], c1 = cs[2 * c + 1];            // cos[8c .. 8c+7]
+    const float4 s0 = cs[16 + 2 * c], s1 = cs[16 + 2 * c + 1];  // sin[8c .. 8c+7]
     int64_t slot = -1;
     if (slot_mapping) {
         slot = slot_mapping[t];
         if (slot >= num_slots) slot = -1;
     }
-    const int c = threadIdx.x & 7;
-    const int group = threadIdx.x >> 3;  // 32 head-groups per pass
-    const int n_heads = H_q + H_kv;
-    // Every lane of a wave runs the same trip count so the DPP reductions see valid
-    // neighbours; lanes whose head is out of range work on head 0 and discard.
+    if (slot >= 0 && v) {
+        uint4* vd = v_cache + slot * H_kv * 16;
+        if ((int)threadIdx.x < v_vecs) vd[threadIdx.x] = v0;
+        const uint4* vs = v + (int64_t)t * v_stride_vec;
+        for (int i = threadIdx.x + blockDim.x; i < v_vecs; i += blockDim.x) vd[i] = vs[i];   // more than 16 kv heads
+    }
+
     const int passes = (n_heads + 31) / 32;
     for (int p = 0; p < passes; ++p) {
         const int hh = p * 32 + group;
         const bool valid = hh < n_heads;
         const int h = valid ? hh : 0;
         const bool is_q = h < H_q;
-        const uint4* src = is_q ? q + (int64_t)t * q_stride_vec + (int64_t)h * 16
-                                : k + (int64_t)t * k_stride_vec + (int64_t)(h - H_q) * 16;
+        const uint4 a_cur = a, b_cur = b;
+        if (p + 1 < passes) {
+            const uint4* nsrc = head_src(hh + 32);
+            a = nsrc[c];
+            b = nsrc[8 + c];
+        }
         uint4 o1, o2;
-        head_norm_rope<NORM>(src, is_q ? q_w : k_w, cs, c, eps, o1, o2);
+        head_norm_rope<NORM>(a_cur, b_cur, is_q ? qwa : kwa, is_q ? qwb : kwb, c0, c1, s0, s1, eps, o1, o2);
         if (!valid) continue;
         if (is_q) {
             uint4* dst = q_out + ((int64_t)t * H_q + h) * 16;
@@ -232,11 +273,6 @@ __global__ __launch_bounds__(256) void qknorm_rope_store_kernel(
                 dst[8 + c] = o2;
             }
         }
-    }
-    if (slot >= 0 && v) {
-        const uint4* vs = v + (int64_t)t * v_stride_vec;
-        uint4* vd = v_cache + slot * H_kv * 16;
-        for (int i = threadIdx.x; i < H_kv * 16; i += blockDim.x) vd[i] = vs[i];
     }
 }
 
