@@ -57,7 +57,12 @@ class Scheduler:
             if budget <= 0 or seq.is_finished:
                 i += 1
                 continue
-            n_new = min(len(seq) - seq.num_computed_tokens, self.long_prefill_token_threshold, budget)
+            # a decode row has exactly one token left; a prompt (or a recomputation) is chunked only when
+            # the threshold is positive, as on admission
+            n_new = len(seq) - seq.num_computed_tokens
+            if 0 < self.long_prefill_token_threshold < n_new:
+                n_new = self.long_prefill_token_threshold
+            n_new = min(n_new, budget)
             got = False
             while True:
                 try:
@@ -112,14 +117,19 @@ class Scheduler:
             budget -= n_new
             self.waiting.popleft()
             self.running.append(seq)
+            if seq.num_preemptions and len(self.running) > 1 and self.running[-2].arrival > seq.arrival:
+                # a re-admitted sequence takes its place by arrival again: otherwise the oldest request
+                # would sit at the tail and be the first victim of the next preemption
+                self.running = deque(sorted(self.running, key=lambda s: s.arrival))
             scheduled.append(seq)
             admitted += 1
         return scheduled, admitted > 0
 
     @staticmethod
     def _pick_victim(running: list[Sequence], current: int) -> Sequence | None:
-        """Youngest running sequence at or after position `current` whose token values are all known
-        on the host (a sequence with a token still in flight cannot be recomputed yet)."""
+        """Youngest running sequence (by arrival: `running` is kept in arrival order) at or after position
+        `current` whose token values are all known on the host (a sequence with a token still in flight
+        cannot be recomputed yet)."""
         for j in range(len(running) - 1, current - 1, -1):
             cand = running[j]
             if not cand.is_finished and cand.num_pending == 0:

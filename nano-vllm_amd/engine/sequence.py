@@ -28,7 +28,8 @@ class Sequence:
     _ids = count()
 
     def __init__(self, prompt_tokens: list[int], sampling_params: SamplingParams | None = None):
-        self.id = f"seq_{next(Sequence._ids)}"
+        self.arrival = next(Sequence._ids)    # arrival order: the scheduler keeps `running` sorted by it
+        self.id = f"seq_{self.arrival}"
         self.status = SequenceStatus.WAITING
         self.prompt_tokens = list(prompt_tokens)
         self.output_tokens: list[int] = []

@@ -77,7 +77,10 @@ class HeadGather:
     """all_gather_heads with buffers that persist across calls: the model path allocates nothing per
     layer (one instance serves every layer of a model: layers run one after another on one stream),
     which also makes the step capturable in a HIP graph once the buffers have reached their size.
-    The buffers grow (a new allocation) only when a step has more tokens than any step before.
+    The buffers grow (a new allocation) only when a step has more tokens than any step before; the
+    outgrown ones stay alive for the life of the object, because decode graphs captured earlier replay
+    their all-gather and copy at the old addresses (freed, that memory could be handed to another tensor
+    and be overwritten on every replay).  `reserve(max_tokens)` before the first capture avoids the growth.
 
     Why the strided copy stays: the all-gather delivers rank-major [N, T, H_q/N, D], o_proj wants
     token-major rows [T, H_q*D].  Consuming the rank-major buffer directly would turn o_proj into N
@@ -88,13 +91,21 @@ class HeadGather:
         self.shard, self.group = shard, group
         self._staging: torch.Tensor | None = None
         self._out: torch.Tensor | None = None
+        self._retired: list[torch.Tensor] = []
+
+    def reserve(self, T: int, hl: int, d: int, dtype: torch.dtype, device) -> None:
+        """Size the buffers for steps of up to T tokens (call before capturing graphs)."""
+        n = self.shard.world
+        device = torch.device(device)
+        if (self._staging is None or self._staging.shape[0] < n * T or self._staging.device != device
+                or self._staging.dtype != dtype or self._staging.shape[1:] != (hl, d)):
+            if self._staging is not None:
+                self._retired += [self._staging, self._out]
+            self._staging = torch.empty((n * T, hl, d), dtype=dtype, device=device)
+            self._out = torch.empty((T, n * hl, d), dtype=dtype, device=device)
 
     def _reserve(self, T: int, hl: int, d: int, like: torch.Tensor) -> None:
-        n = self.shard.world
-        if (self._staging is None or self._staging.shape[0] < n * T or self._staging.device != like.device
-                or self._staging.dtype != like.dtype or self._staging.shape[1:] != (hl, d)):
-            self._staging = torch.empty((n * T, hl, d), dtype=like.dtype, device=like.device)
-            self._out = torch.empty((T, n * hl, d), dtype=like.dtype, device=like.device)
+        self.reserve(T, hl, d, like.dtype, like.device)
 
     def __call__(self, o_local: torch.Tensor) -> torch.Tensor:
         if self.shard.world == 1:

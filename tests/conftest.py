@@ -54,3 +54,50 @@ def make_paged_problem(seed, n_qs, n_ks, H_q, H_kv, block_size, num_blocks, D=12
     if device != "cpu":
         p = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in p.items()}
     return p
+
+
+# ------------------------------------------------------------------ scale-aware attention bound
+C_ROW = 0.03        # a correct kernel stays below about a third of this (bf16 output rounding of a 3-sigma
+                    # element is 0.006 rms; bf16 probabilities add about 0.002 rms)
+
+
+def bf16_ulp(x: float) -> float:
+    """Spacing of bfloat16 numbers at magnitude x (8 significant bits)."""
+    import math
+    return 2.0 ** (math.floor(math.log2(max(abs(x), 2.0 ** -126))) - 7)
+
+
+def row_bounds(ref: torch.Tensor, c: float = C_ROW) -> torch.Tensor:
+    """Per output row (last dimension = head_dim): max(one bf16 ulp of max|ref|, c * rms(ref)).
+    A row that averages n random value rows has rms ~ sqrt(e / n), so a fixed absolute bound says less
+    and less as contexts grow; this one scales with the answer."""
+    ref = ref.float()
+    amax = ref.abs().amax(dim=-1)
+    ulp = torch.exp2(torch.floor(torch.log2(amax.clamp_min(2.0 ** -126))) - 7)
+    rms = ref.pow(2).mean(dim=-1).sqrt()
+    return torch.maximum(ulp, c * rms)
+
+
+def assert_rows_close(out: torch.Tensor, ref: torch.Tensor, name, c: float = C_ROW, abs_tol: float = 2e-2) -> float:
+    """Both bars: the fixed max-abs tolerance and the per-row scale-aware one.  Returns the worst
+    ratio err / bound (a correct kernel is expected below about 1/3)."""
+    out, ref = out.float().cpu(), ref.float().cpu()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    err = (out - ref).abs().amax(dim=-1)
+    assert torch.isfinite(out).all(), (name, "non-finite output")
+    assert err.max().item() <= abs_tol, (name, "max-abs", err.max().item())
+    ratio = err / row_bounds(ref, c)
+    worst = ratio.max().item()
+    assert worst <= 1.0, (name, "row error / scale-aware bound", worst, "at", int(ratio.argmax()))
+    return worst
+
+
+def assert_bound_is_sensitive(ref: torch.Tensor, ref_damaged: torch.Tensor, name, c: float = C_ROW) -> float:
+    """The check must be able to fail: the oracle's own answer with one 256-key block taken out of the
+    sequence (``ref_damaged``) has to violate the bound on every row given.  Returns the smallest ratio."""
+    ref, ref_damaged = ref.float().cpu(), ref_damaged.float().cpu()
+    err = (ref_damaged - ref).abs().amax(dim=-1)
+    ratio = err / row_bounds(ref, c)
+    least = ratio.min().item()
+    assert least > 1.0, (name, "insensitive: dropping a key block stays inside the bound", least)
+    return least

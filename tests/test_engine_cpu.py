@@ -349,6 +349,51 @@ def test_preemption_counts_and_order():
     assert b in seqs and admitted and b.num_scheduled_tokens == len(b) - b.num_computed_tokens
 
 
+def test_threshold_zero_means_no_chunking_and_decode_rows_still_get_one_token():
+    """long_prefill_token_threshold <= 0 switches chunking off (admission treats it so): a running row must
+    then still get its decode token (or the rest of its prompt), not a zero-token slot that never advances."""
+    sched = Scheduler(8, 4, max_num_batched_tokens=6, long_prefill_token_threshold=0, eos=-1)
+    a = Sequence(list(range(9)), SamplingParams(0.0, 3))
+    sched.add(a)
+    seqs, admitted = sched.schedule()
+    assert seqs == [a] and admitted and a.num_scheduled_tokens == 6           # the budget, not the threshold, cuts
+    sched.update_from_output(seqs, [None])
+    seqs, _ = sched.schedule()
+    assert seqs == [a] and a.num_scheduled_tokens == 3                        # the rest of the prompt in one piece
+    sched.update_from_output(seqs, [50])
+    for want_len in (11, 12):
+        seqs, _ = sched.schedule()
+        assert seqs == [a] and a.num_scheduled_tokens == 1                    # a decode row: exactly one token
+        sched.update_from_output(seqs, [51])
+        assert len(a) == want_len
+    assert a.is_finished and sched.is_finished()
+
+
+def test_preemption_victims_are_chosen_by_arrival_not_by_queue_position():
+    """Three requests under sustained cache pressure: a re-admitted sequence goes back to its place by
+    arrival in `running`, so the oldest request is never the first victim again and no sequence is
+    recomputed over and over while newer ones proceed."""
+    sched = Scheduler(6, 4, max_num_batched_tokens=64, long_prefill_token_threshold=64, eos=-1)
+    seqs_all = [Sequence(list(range(10 * i, 10 * i + 7)), SamplingParams(0.0, 12)) for i in range(3)]
+    for s_ in seqs_all:
+        sched.add(s_)
+    steps = 0
+    while not sched.is_finished():
+        seqs, _ = sched.schedule()
+        assert seqs, "no progress"
+        arrivals = [s_.arrival for s_ in sched.running]
+        assert arrivals == sorted(arrivals), "running must stay in arrival order"
+        sched.update_from_output(seqs, [7 if s_.num_computed_tokens + s_.num_scheduled_tokens >= len(s_) else None
+                                        for s_ in seqs])
+        steps += 1
+        assert steps < 400
+    a, b, c = seqs_all
+    assert a.num_preemptions == 0, "the oldest request must never be a victim while younger ones run"
+    assert b.num_preemptions <= 2 and c.num_preemptions <= 3, (b.num_preemptions, c.num_preemptions)
+    assert all(len(s_.output_tokens) == 12 for s_ in seqs_all)
+    assert sched.block_manager.num_free_blocks == 6
+
+
 def test_requests_that_can_never_fit_are_refused():
     eng, cfg = _tiny_engine(16, 4)
     with pytest.raises(ValueError, match="KV-cache blocks"):

@@ -9,7 +9,8 @@ attention max-abs <= 2e-2 against the fp32 oracle.
 import pytest
 import torch
 
-from conftest import bits
+from conftest import assert_bound_is_sensitive, assert_rows_close, bits
+from longctx_util import check_rows_with_sensitivity
 from oracle import ref_attention, ref_layers, ref_modules
 
 pytestmark = pytest.mark.gpu
@@ -42,21 +43,20 @@ def long_cache():
     return dict(k=k, v=v, bt=bt, q=q, n_k=n_k, bs=bs, per=per, NB=NB)
 
 
-def _oracle_row(c, b, hq, n_k, G=4):
-    """fp32 oracle output of (sequence b, query head hq): the oracle run on that head's slice of the cache."""
-    hkv = hq // G
-    rows = c["bt"][b].long()
-    kc = c["k"][:, :, hkv:hkv + 1].cpu()
-    vc = c["v"][:, :, hkv:hkv + 1].cpu()
-    return ref_attention.paged_attention_ref(c["q"][b:b + 1, hq:hq + 1], kc, vc, torch.tensor([0, 1], dtype=torch.int32),
-                                             torch.tensor([0, n_k], dtype=torch.int32), rows[None].to(torch.int32),
-                                             128 ** -0.5)[0, 0]
+def _samples(c, B, lens, G=4):
+    """Every sequence x 4 query heads, walking over all 8 kv heads as b grows."""
+    return [(b, (b + 9 * i) % 32, c["bt"][b], lens[b]) for b in range(B) for i in range(4)]
 
 
+@pytest.mark.parametrize("peaked", [False, True])
 @pytest.mark.parametrize("B", [1, 4, 8])
-def test_config5_decode_32k_context(ops, long_cache, B):
-    """ctx 32768, H 32/8, B sequences per replica: sampled (sequence, head) rows against the oracle,
-    V == const gives const, and a permutation of the physical blocks leaves the output bit-identical.
+def test_config5_decode_32k_context(ops, long_cache, B, peaked):
+    """ctx 32768, H 32/8, B sequences per replica: every sequence x 4 heads against the oracle under the
+    scale-aware bound (a 32 k-key average of N(0,1) values has rms 0.009: the fixed 2e-2 is two sigma of
+    the ANSWER there and cannot fail), with the bound's sensitivity shown on every sample (the oracle's
+    own answer without one 256-key block violates it); ``peaked`` multiplies the softmax scale by 4 so
+    that a handful of keys anywhere in the context carry the weight and outputs are O(1).  V == const
+    gives const, and a permutation of the physical blocks leaves the output bit-identical.
     B = 1 and B = 4 cut every (sequence, kv head) into 32 key chunks (workgroup and wave work items
     respectively) and combine them with the 8-group merge; B = 8 uses 16 chunks."""
     from nanovllm_amd import _lib
@@ -64,17 +64,21 @@ def test_config5_decode_32k_context(ops, long_cache, B):
     n_k, per = c["n_k"], c["per"]
     ns = (_lib.lib().nv_attn_decode_workspace_bytes(B, 32, 8, 128, n_k) - 65536) // (B * 32 * 132 * 4)
     assert ns == (16 if B == 8 else 32), ns
+    scale = 128 ** -0.5 * (4.0 if peaked else 1.0)
     lens = [n_k - 255 * i for i in range(B)]                       # ragged tails inside the last blocks
     cu_k = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=DEV)
     bt = c["bt"][:B].to(DEV)
     q = c["q"][:B].to(DEV)
-    o = ops.attn_decode_paged(q, c["k"], c["v"], cu_k, bt, n_k, 128 ** -0.5)
-    for b, hq in {(0, 0), (B - 1, 31), (B // 2, 13)}:
-        ref = _oracle_row(c, b, hq, lens[b])
-        err = (o[b, hq].float().cpu() - ref).abs().max().item()
-        assert err <= TOL, (B, b, hq, err)
+    o = ops.attn_decode_paged(q, c["k"], c["v"], cu_k, bt, n_k, scale)
+    oc = o.cpu()
+    worst, least = check_rows_with_sensitivity(lambda t, h: oc[t, h], _samples(c, B, lens), c["q"], c["k"], c["v"], 4,
+                                               scale, f"config5 B={B} peaked={peaked}", peaked,
+                                               assert_rows_close, assert_bound_is_sensitive)
+    print(f"config5 B={B} peaked={peaked}: worst err/bound {worst:.3f}, least damage/bound {least:.1f}")
+    if peaked:
+        return
     const = torch.full_like(c["v"], 0.625)
-    oc = ops.attn_decode_paged(q, c["k"], const, cu_k, bt, n_k, 128 ** -0.5)
+    oc = ops.attn_decode_paged(q, c["k"], const, cu_k, bt, n_k, scale)
     del const
     assert (oc.float() - 0.625).abs().max().item() <= 4e-3
     g = torch.Generator().manual_seed(B)
@@ -84,8 +88,51 @@ def test_config5_decode_32k_context(ops, long_cache, B):
     k2 = c["k"][perm.to(DEV)]
     v2 = c["v"][perm.to(DEV)]
     bt2 = inv[c["bt"][:B].long()].to(torch.int32).to(DEV)
-    o2 = ops.attn_decode_paged(q, k2, v2, cu_k, bt2, n_k, 128 ** -0.5)
+    o2 = ops.attn_decode_paged(q, k2, v2, cu_k, bt2, n_k, scale)
     assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("single", [0, 1])
+@pytest.mark.parametrize("B", [1, 4, 8])
+def test_config5_decode_32k_spike_key_in_every_key_chunk(ops, long_cache, B, single):
+    """Every key chunk of every (sequence, kv head) must reach the combine: one key whose score exceeds all
+    others by > 25 (its K row = 3 q of the kv head's first query head) is planted in chunk
+    (rot + b * 8 + hkv) % 32 for rot = 0..31, so that each pair sees it in each chunk once; the output of that
+    query head then IS the key's V row (the rest of the softmax weighs < 1e-9), bit for bit.  A chunk that
+    is dropped, combined with a wrong weight or read from a wrong block shows as a mismatch.  Both combine
+    forms: second launch (single = 0) and inside the launch (single = 1)."""
+    from nanovllm_amd import _lib
+    c = long_cache
+    n_k, bs, G, H_kv = c["n_k"], c["bs"], 4, 8
+    lens = [n_k - 255 * i for i in range(B)]
+    cu_k = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32, device=DEV)
+    bt = c["bt"][:B].to(DEV)
+    q = c["q"][:B].to(DEV)
+    spike = (q[:, ::G].float() * 3).bfloat16()                     # [B, H_kv, D]
+    nchunk = 32
+    lens_d = torch.tensor(lens, device=DEV)
+    bsel = torch.arange(B, device=DEV)[:, None].expand(B, H_kv)
+    hsel = torch.arange(H_kv, device=DEV)[None, :].expand(B, H_kv)
+    _lib.set_tuning(decode_single_launch=single)
+    try:
+        for rot in range(nchunk):
+            chunk = (rot + bsel * H_kv + hsel) % nchunk
+            pos = torch.minimum(chunk * (n_k // nchunk) + 517, lens_d[:, None] - 2)     # inside the sequence
+            blk = bt.long().gather(1, pos // bs)                               # [B, H_kv] physical blocks
+            off = pos % bs
+            saved = c["k"][blk, off, hsel].clone()
+            c["k"][blk, off, hsel] = spike
+            try:
+                o = ops.attn_decode_paged(q, c["k"], c["v"], cu_k, bt, n_k, 128 ** -0.5)
+                want = c["v"][blk, off, hsel]                                  # [B, H_kv, D]
+                got = o[:, ::G]
+                bad = (bits(got) != bits(want)).any(dim=-1).nonzero().tolist()
+                assert not bad, (f"B={B} single={single} rot={rot}: (sequence, kv head) pairs whose output is not the "
+                                 f"spike key's V row", bad[:8])
+            finally:
+                c["k"][blk, off, hsel] = saved
+    finally:
+        _lib.set_tuning()
 
 
 def test_llama3_rotary_bit_exact_up_to_position_131071(ops):

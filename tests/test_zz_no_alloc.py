@@ -28,11 +28,20 @@ def _both(dll, p, H_q, H_kv, bs):
     o_st = torch.full_like(p["q"], float("nan"))
     rc = dll.nv_attn_decode_paged(*common, o_ws.data_ptr(), *meta, o_ws.stride(0), ws.data_ptr(), ws.numel(), stream)
     assert rc == 0, dll.nv_last_error()
-    before = torch.cuda.memory_allocated()
+    # warm-up call: the per-device address lookup (and HIP's lazy loading of the code object) happen here
     rc = dll.nv_attn_decode_paged_static(*common, o_st.data_ptr(), *meta, o_st.stride(0), stream)
     assert rc == 0, dll.nv_last_error()
-    assert torch.cuda.memory_allocated() == before
     torch.cuda.synchronize()
+    o_st.fill_(float("nan"))
+    torch.cuda.synchronize()
+    # free device memory as the driver sees it (torch's own counters cannot see a hipMalloc inside the library)
+    free_before = torch.cuda.mem_get_info()[0]
+    torch_before = torch.cuda.memory_allocated()
+    rc = dll.nv_attn_decode_paged_static(*common, o_st.data_ptr(), *meta, o_st.stride(0), stream)
+    assert rc == 0, dll.nv_last_error()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "the allocation-free entry point changed the free device memory"
+    assert torch.cuda.memory_allocated() == torch_before
     return o_ws, o_st, need
 
 

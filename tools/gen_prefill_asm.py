@@ -15,11 +15,15 @@ query rows (two 32-row blocks qb) of one query head and the whole 512-entry regi
         v[192:223]  P^T fragments      P(ks, qb, w)  = 192 + 8 ks + 4 qb + w
         v[224:255]  softmax state, lane-constant addresses, temporaries
 
-Softmax without a multiply-add per score: the Q fragments are multiplied by scale * log2(e) once per item
-(bf16), and every S^T accumulator chain STARTS from the block that holds minus the running maximum of its
-query rows (the MFMA's C operand), so an accumulator is already  scale * log2(e) * q.k - m  and the
-probability is exp2 of it.  The running maximum is raised (rarely: when a tile maximum exceeds it by more than
-2^8) in a side path that also shifts the tile's accumulators and the -m blocks.
+Softmax scaling: c = scale * log2(e) is split into c = 2^e * r with 1 <= r < 2.  The Q fragments are multiplied
+by 2^e once per item (exact in bf16: no rounding is added to the scores, which stay the fp32 sums of exact bf16
+products that flash-attn's fp32 scaling sees), every S^T accumulator chain STARTS from the block that holds minus
+the running maximum of its query rows (the MFMA's C operand, in the same 2^e units), so an accumulator is already
+2^e * q.k - m, and the probability is exp2(r * accumulator): one v_mul_f32 per score in the exp stream (PF_EXACT=1,
+the default).  PF_EXACT=0 folds all of c into the bf16 Q fragments instead and drops that multiply: 6 - 8 % faster,
+but the rounding of c * q to bf16 perturbs every score by about 2^-9 of its magnitude, which shows on peaked
+softmax rows.  The running maximum is raised (rarely: when a tile maximum exceeds it by more than 2^8) in a side
+path that also shifts the tile's accumulators and the -m blocks.
 
 Tile j (64 keys) is processed by a two-phase software pipeline; iteration j of the loop is
   phase 1: 32 MFMAs  S(j) = K(j) Q^T - m   beside  the rest of exp / row sums / bf16 packing of S(j-1),
@@ -73,6 +77,7 @@ S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
 S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
 S_SAVE = 82                    # s[82:83] saved exec
 S_LAST = 84                    # index of the next item while an epilogue prefetches for it
+S_R = 85                       # r = scale * log2(e) / 2^e, 1 <= r < 2 (fp32 bits): the exp stream's multiplier
 
 # LDS layout (bytes)
 SLOT = 32768                   # one K tile (16 KiB) + one V tile (16 KiB)
@@ -159,14 +164,15 @@ def k_reads(slot):
     return out
 
 
+EXACT = os.environ.get("PF_EXACT", "1") != "0"   # fp32 score scaling (one multiply per score); 0: all of c in bf16 Q
 N_P2 = int(os.environ.get("PF_NP2", "11"))   # value pairs of key block 0 whose exp stream runs in phase 2
 N_B = int(os.environ.get("PF_NB", "18"))     # entries of that stream that run beside MFMAs 10..15
 P1_DMA, P1_VR = (int(x) for x in os.environ.get("PF_P1MIX", "3,4").split(","))   # phase 1: a DMA / V read every n-th entry
 
 
 def exp_pairs(buf, kb):
-    """Per value pair of the S registers of key block kb: (exp a, exp b, add a, add b, cvt).  The accumulators
-    already hold scale * log2(e) * q.k - m."""
+    """Per value pair of the S registers of key block kb: (exp a, exp b, add a, add b, cvt, mul a, mul b).  The
+    accumulators hold 2^e * q.k - m; the multiplies (exact mode) bring them to scale * log2(e) * q.k - r m."""
     pairs = []
     for qb in range(2):
         for i in range(0, 16, 2):
@@ -175,19 +181,27 @@ def exp_pairs(buf, kb):
             w = (i & 7) >> 1
             pairs.append((f"v_exp_f32 v{ra}, v{ra}", f"v_exp_f32 v{rb}, v{rb}",
                           f"v_add_f32 v{L[qb]}, v{L[qb]}, v{ra}", f"v_add_f32 v{L[qb] + 1}, v{L[qb] + 1}, v{rb}",
-                          ("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}")))
+                          ("cvt", f"v_cvt_pk_bf16_f32 v{P(ks, qb, w)}, v{ra}, v{rb}"),
+                          f"v_mul_f32 v{ra}, s{S_R}, v{ra}", f"v_mul_f32 v{rb}, s{S_R}, v{rb}"))
     return pairs
 
 
 def flatten_pairs(pairs):
     """Skewed by one pair: the two exponentials of a pair are not neighbours and nothing reads an
-    exponential in the instruction after it."""
+    exponential in the instruction after it; in exact mode the multiplies of the NEXT pair sit behind the
+    exponentials of this one."""
     out = []
-    for n, (ea, eb, aa, ab, cv) in enumerate(pairs):
+    if pairs and EXACT:
+        out += [pairs[0][5], pairs[0][6]]
+    for n, (ea, eb, aa, ab, cv, ma, mb) in enumerate(pairs):
         out.append(ea)
+        if EXACT and n + 1 < len(pairs):
+            out.append(pairs[n + 1][5])
         if n > 0:
             out.append(pairs[n - 1][2])
         out.append(eb)
+        if EXACT and n + 1 < len(pairs):
+            out.append(pairs[n + 1][6])
         if n > 0:
             out.append(pairs[n - 1][3])
             out.append(pairs[n - 1][4])
@@ -405,8 +419,14 @@ def slow_max(o: Out, buf, tag):
     blk = [f".Lpf_slow_{tag}:"]
     for qb in range(2):
         blk.append(f"  v_max_f32 v{T[qb]}, 0, v{TM[qb]}")
-    for qb in range(2):
-        blk.append(f"  v_exp_f32 v{AL[qb]}, -v{T[qb]}")
+    if EXACT:
+        for qb in range(2):
+            blk.append(f"  v_mul_f32 v{AL[qb]}, s{S_R}, v{T[qb]}")      # the maxima are in 2^e units: r * shift
+        for qb in range(2):
+            blk.append(f"  v_exp_f32 v{AL[qb]}, -v{AL[qb]}")
+    else:
+        for qb in range(2):
+            blk.append(f"  v_exp_f32 v{AL[qb]}, -v{T[qb]}")
     for qb in range(2):
         for kb in range(2):
             for i in range(16):
@@ -567,6 +587,11 @@ def gen_setup(o: Out):
     o.e(f"v_mov_b32 v{NINF}, 0xff800000")
     o.c("first item: its descriptor; its Q fragments travel to the K fragment registers (scaled into place later)")
     read_descriptor(o, S_ITEM)
+    o.c("word 5 of the first descriptor: r (the operand list is as long as the free scalar registers allow)")
+    o.e(f"ds_read_b32 v{T[0]}, v{T[5]} offset:20")
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e("s_nop 1")
+    o.e(f"v_readfirstlane_b32 s{S_R}, v{T[0]}")
     lane_consts(o)
     q_fetch(o, S_RW0, K(0, 0))
     if EXIT_AT == "setup":
@@ -825,6 +850,8 @@ def partial_state_store():
     k = 0
     for qb in range(2):
         b += [f"  v_sub_f32 v{64 + 2 * qb}, 0, v{NMB(qb)}", f"  v_mov_b32 v{65 + 2 * qb}, v{L[qb]}"]
+        if EXACT:
+            b += [f"  v_mul_f32 v{64 + 2 * qb}, s{S_R}, v{64 + 2 * qb}"]     # the running maximum in log2 units
         for d in range(4):
             for g in range(4):
                 r0 = 4 * (k % 16)
