@@ -11,8 +11,8 @@ constexpr float kRescaleThreshold = 8.0f;   // log2 units: P stays below 2^8 bet
 
 constexpr int kPartStride = kHeadDim + 4;    // fp32 per partial state: 128 acc + m + l + 2 pad
 // hand-scheduled kernel: one unit per (wave, key range) = its 64 rows in register order
-// [qb 2][d 4][g 4][lane 64][4 floats] followed by [qb 2][lane 64][m, l]
-constexpr int kImageAcc = 2 * 4 * 4 * 64 * 16;
+// [qb 2][d 4][half 2][lane 64][8 bf16] followed by [qb 2][lane 64][m, l] (fp32)
+constexpr int kImageAcc = 2 * 4 * 2 * 64 * 16;
 constexpr int kImageUnit = kImageAcc + 2 * 64 * 8;
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -38,7 +38,7 @@ struct PrefillParams {
     int skip_single;
     // key-range splitting (launches with too few workgroups for the chip)
     float* part;          // [total_q, H_q, nsplit, kPartStride] fp32 partial states (hand-scheduled kernel:
-                          // [grid_base * 4 waves, nsplit] units of kImageUnit bytes)
+                          // [grid_base * 4 waves, nsplit] units of kImageUnit bytes, accumulators in bf16)
     int nsplit;           // 1: results are written directly
     int tiles_per_split;  // 64-key tiles per split
     int grid_base;        // workgroups per split (multiple of 8)

@@ -638,13 +638,8 @@ def gen_item_prologue(o: Out):
     o.e("s_waitcnt lgkmcnt(0)")
     for qb in range(2):
         o.e(f"v_add_u32 v{QPOS[qb]}, s{S_ITEMBASE}, v{QPOS[qb]}")
-    # tiles 0, 1 of the first item are fetched here; later items had them prefetched by the item before
-    o.e(f"s_cmp_lg_u32 s{S_ITEM}, 0")
-    o.e("s_cbranch_scc1 .Lpf_prefetched")
-    tile_fetch_const(o, 0, "K", 0, DOFFK, "pro_k0", False)
-    tile_fetch_const(o, 0, "V", 0, DOFFV, "pro_v0", False)
-    tile_fetch_const(o, 1, "K", 1, DOFFK, "pro_k1", False)
-    o.label(".Lpf_prefetched")
+    # K(0), V(0) -> slot 0 and K(1) -> slot 1 are in flight or have landed: the code in front of the asm body
+    # requested them for the first item, the epilogue of the item before for every later one
     o.e("s_waitcnt vmcnt(0)")
     q_prescale(o)
     o.e("s_barrier")
@@ -835,32 +830,41 @@ def gen_epilogue(o: Out, qbuf):
 
 
 def partial_state_store():
-    """Key-range split: the wave's rows leave as an unnormalised fp32 state in the order the registers hold it,
-    one 33,792-byte unit per (wave, key range) at s[S_OSEQ:S_OSEQ+1]:
-        [qb 2][d 4][g 4][lane 64][4 floats]   lane (r, h) holds dims 32 d + 8 g + 4 h .. + 3 of row 32 qb + r
-        [qb 2][lane 64][m, l]                 at byte 32768 (the same pair in both lanes of a row)
+    """Key-range split: the wave's rows leave as an unnormalised state in the order the registers hold it, one
+    17,408-byte unit per (wave, key range) at s[S_OSEQ:S_OSEQ+1]:
+        [qb 2][d 4][half 2][lane 64][8 bf16]   lane (r, h) holds accumulators i = 8 half .. 8 half + 7 of block
+                                               (qb, d): dims 32 d + 8 (i >> 2) + 4 h + (i & 3) of row 32 qb + r
+        [qb 2][lane 64][m, l]  fp32            at byte 16384 (the same pair in both lanes of a row)
     so every store instruction writes 1 KiB (512 B) of consecutive memory; attn_prefill_merge_image_kernel reads
-    the units back.  All 64 rows are written (rows behind the end of the sequence repeat its last row; the merge
+    the units back.  The accumulators are rounded to bf16 (a relative 2^-9 per key range, the size of the output's
+    own rounding; bf16 has the exponent range of fp32, so unnormalised sums fit); m and l stay fp32.  The state
+    traffic bounds a split launch (every byte is written and read once, at memory speed), which is why it is
+    halved here.  All 64 rows are written (rows behind the end of the sequence repeat its last row; the merge
     does not store them).  Out of line; v[0:67] are free here."""
     b = [".Lpf_fin_part:"]
     b += [f"  s_mov_b64 s[{S_T0 + 2}:{S_T0 + 3}], s[{S_OSEQ}:{S_OSEQ + 1}]",
           f"  v_mbcnt_lo_u32_b32 v{T[0]}, -1, 0", f"  v_mbcnt_hi_u32_b32 v{T[0]}, -1, v{T[0]}",
           f"  v_lshlrev_b32 v{T[3]}, 4, v{T[0]}",                                       # 16 bytes per lane
-          f"  v_lshlrev_b32 v{T[2]}, 3, v{T[0]}", f"  v_add_u32 v{T[2]}, 0x8000, v{T[2]}"]  # (m, l) pairs behind the image
+          f"  v_lshlrev_b32 v{T[2]}, 3, v{T[0]}", f"  v_add_u32 v{T[2]}, 0x4000, v{T[2]}"]  # (m, l) pairs behind the image
     k = 0
     for qb in range(2):
         b += [f"  v_sub_f32 v{64 + 2 * qb}, 0, v{NMB(qb)}", f"  v_mov_b32 v{65 + 2 * qb}, v{L[qb]}"]
         if EXACT:
             b += [f"  v_mul_f32 v{64 + 2 * qb}, s{S_R}, v{64 + 2 * qb}"]     # the running maximum in log2 units
         for d in range(4):
-            for g in range(4):
-                r0 = 4 * (k % 16)
-                k += 1
-                for i in range(4):
-                    b.append(f"  v_accvgpr_read_b32 v{r0 + i}, a{O(qb, d, 4 * g + i)}")
-                b.append("  s_nop 0")
-                b.append(f"  global_store_dwordx4 v{T[3]}, v[{r0}:{r0 + 3}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{g * 1024}")
-            b.append(f"  v_add_u32 v{T[3]}, 0x1000, v{T[3]}")
+            pk = 16 + 8 * (k % 6)          # packed registers rotate: a store reads its data some time after issue
+            k += 1
+            for i in range(16):
+                b.append(f"  v_accvgpr_read_b32 v{i}, a{O(qb, d, i)}")
+            b.append("  s_nop 1")
+            for i in range(8):
+                b.append(f"  v_cvt_pk_bf16_f32 v{pk + i}, v{2 * i}, v{2 * i + 1}")
+            b.append("  s_nop 0")
+            for half in range(2):
+                b.append(f"  global_store_dwordx4 v{T[3]}, v[{pk + 4 * half}:{pk + 4 * half + 3}], "
+                         f"s[{S_T0 + 2}:{S_T0 + 3}] offset:{(d & 1) * 2048 + half * 1024}")
+            if d & 1:
+                b.append(f"  v_add_u32 v{T[3]}, 0x1000, v{T[3]}")
         b.append(f"  global_store_dwordx2 v{T[2]}, v[{64 + 2 * qb}:{65 + 2 * qb}], s[{S_T0 + 2}:{S_T0 + 3}] offset:{qb * 512}")
     b.append("  s_branch .Lpf_fin_next")
     _ool.append(b)
