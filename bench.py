@@ -414,15 +414,37 @@ def cpu_baseline_other(seconds_each: float = 3.0):
     return out
 
 
+def _device_identity(dev):
+    pr = torch.cuda.get_device_properties(dev)
+    ident = {"name": pr.name, "index": dev.index}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        if hasattr(pr, key):
+            ident[key] = str(getattr(pr, key))
+    return ident
+
+
+def _gather_objects(dist, world, obj):
+    if dist is None:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+
+
 def tp_bench(args, dev, rank, world, dist):
     """Head-sharded decode attention + all-gather of head outputs (BASELINE config 4 shapes:
     Qwen3-32B attention, H_q=64, H_kv=8, D=128, batch 256, ctx 2048, block 256).  Rank r holds kv heads
     [r*8/N, (r+1)*8/N) of every layer's cache; metadata is replicated; per layer: local decode
-    attention, then one all-gather [T, H_q/N, D] -> [T, H_q, D].  `layers` is reduced from the
-    model's 64 to bound memory and time; per-layer work is what is reported."""
+    attention, then one all-gather [T, H_q/N, D] -> [T, H_q, D] and the strided copy into head order.
+    A step is the model's 64 launches, cycling over `tp_layers` distinct layer caches (each larger than
+    the last-level cache, so every launch streams from HBM).
+    The record verifies itself: one more layer is built identically on every rank from a seeded device
+    generator (all heads), every rank attends over its shard of it, the head outputs are gathered, and rank 0
+    compares them with ONE launch over all heads on its own GPU; the ranks' device identities are gathered to
+    show that they are distinct devices."""
     from nanovllm_amd import _lib
     from nanovllm_amd.parallel import HeadShard, all_gather_heads
-    H_Q, H_KV, D, BS, B, CTX, L = 64, 8, 128, 256, 256, 2048, args.tp_layers
+    H_Q, H_KV, D, BS, B, CTX, L, MODEL_L = 64, 8, 128, 256, 256, 2048, args.tp_layers, 64
     shard = HeadShard(rank, world, H_Q, H_KV)
     hq, hkv = shard.local_heads, shard.local_kv_heads
     g = torch.Generator().manual_seed(1234)                      # same tables on every rank
@@ -445,47 +467,143 @@ def tp_bench(args, dev, rank, world, dist):
     ws = torch.empty(max(dll.nv_attn_decode_workspace_bytes(B, hq, hkv, D, CTX), 16), dtype=torch.uint8, device=dev)
     gloo = dist is not None and dist.get_backend() == "gloo"
 
-    def step(gather):
-        for l in range(L):
-            rc = dll.nv_attn_decode_paged(q.data_ptr(), cache[0, l].data_ptr(), cache[1, l].data_ptr(), o_local.data_ptr(),
-                                          cu_q.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B, nb_seq, CTX, hq, hkv, D,
-                                          NB, BS, D ** -0.5, q.stride(0), o_local.stride(0), ws.data_ptr(), ws.numel(),
-                                          stream)
-            if rc != 0:
-                _lib.check(rc, "nv_attn_decode_paged")
-            if gather and gloo:          # rehearsal only: gloo gathers host tensors
+    def attend(qt, kc, vc, ot, heads_q, heads_kv, wsp):
+        rc = dll.nv_attn_decode_paged(qt.data_ptr(), kc.data_ptr(), vc.data_ptr(), ot.data_ptr(),
+                                      cu_q.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B, nb_seq, CTX, heads_q, heads_kv, D,
+                                      NB, BS, D ** -0.5, qt.stride(0), ot.stride(0), wsp.data_ptr(), wsp.numel(), stream)
+        if rc != 0:
+            _lib.check(rc, "nv_attn_decode_paged")
+
+    def step(mode):
+        """mode 0: attention only; 1: + all-gather into the rank-major staging buffer; 2: + the copy into head order."""
+        for i in range(MODEL_L):
+            l = i % L
+            attend(q, cache[0, l], cache[1, l], o_local, hq, hkv, ws)
+            if mode and gloo:            # rehearsal only: gloo gathers host tensors
                 o_full.copy_(all_gather_heads(o_local.cpu(), shard))
-            elif gather:
+            elif mode == 1:
+                dist.all_gather_into_tensor(staging, o_local)
+            elif mode == 2:
                 all_gather_heads(o_local, shard, out=o_full, staging=staging)
 
-    def timed(gather):
+    def timed(mode):
         for _ in range(2):
-            step(gather)
+            step(mode)
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(gather)
+            step(mode)
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
         return reduce_scalar(dist, dev, time.perf_counter() - t0, "max") / args.steps
 
-    t_attn = timed(False)
-    t_full = timed(world > 1)
+    t_attn = timed(0)
+    t_gather = timed(1) if world > 1 else t_attn
+    t_full = timed(2) if world > 1 else t_attn
+    del cache
+    torch.cuda.empty_cache()
+
+    # ---- self-check on one more layer, identical on every rank ----
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    k_all = torch.randn(NB, BS, H_KV, D, generator=gen, device=dev, dtype=torch.float32).bfloat16()
+    v_all = torch.randn(NB, BS, H_KV, D, generator=gen, device=dev, dtype=torch.float32).bfloat16()
+    q_all = torch.randn(B, H_Q, D, generator=gen, device=dev, dtype=torch.float32).bfloat16()
+    k_my, v_my = shard.slice_kv(k_all).contiguous(), shard.slice_kv(v_all).contiguous()
+    attend(shard.slice_q(q_all), k_my, v_my, o_local, hq, hkv, ws)
+    if world == 1:
+        gathered = o_local
+    elif gloo:
+        gathered = all_gather_heads(o_local.cpu(), shard).to(dev)
+    else:
+        gathered = all_gather_heads(o_local, shard, out=o_full, staging=staging)
+    verified, max_diff, bit_identical = True, 0.0, True
+    if rank == 0:
+        want = torch.empty(B, H_Q, D, dtype=torch.bfloat16, device=dev)
+        ws_all = torch.empty(max(dll.nv_attn_decode_workspace_bytes(B, H_Q, H_KV, D, CTX), 16), dtype=torch.uint8, device=dev)
+        attend(q_all, k_all, v_all, want, H_Q, H_KV, ws_all)
+        torch.cuda.synchronize(dev)
+        max_diff = (want.float() - gathered.float()).abs().max().item()
+        bit_identical = bool(torch.equal(want.view(torch.int16), gathered.view(torch.int16)))
+        # the launch plan (key split) follows the kv heads per GPU, so the fp32 summation order may differ
+        verified = bool(max_diff <= 1e-2 and torch.isfinite(gathered.float()).all())
+    del k_all, v_all, k_my, v_my
+    torch.cuda.empty_cache()
+    devices = _gather_objects(dist, world, _device_identity(dev))
+    ids = [d.get("uuid") or d.get("pci_bus_id") or f"index {d.get('index')}" for d in devices]
     bytes_layer_all = B * (2 * CTX * H_KV * D * 2 + 2 * H_Q * D * 2 + 4 * nb_seq + 8)     # all ranks together
     if dist is not None:
         assert dist.get_world_size() == world == args.gpus, "process group size differs from --gpus"
-    return {"world_size": world,
-            "ms_allgather_per_layer": round(max(t_full - t_attn, 0.0) / L * 1e3, 4),
-            "workload": f"Qwen3-32B attention shapes, decode batch {B}, ctx {CTX}, block {BS}, {L} layers, "
-                        f"kv heads sharded {H_KV}/{world} per GPU, RCCL all-gather of o per layer",
-            "ms_per_layer_attn_only": round(t_attn / L * 1e3, 4),
-            "ms_per_layer_with_allgather": round(t_full / L * 1e3, 4),
-            "attn_GBps_all_gpus": round(bytes_layer_all * L / t_full / 1e9, 1),
-            "allgather_bytes_per_layer": B * H_Q * D * 2,
-            "tok_per_s_attention_path": round(B / (t_full / L * 64), 1)}
+    rec = {"world_size": world,
+           "verified": verified, "verify_max_abs_diff": round(max_diff, 6), "verify_bit_identical": bit_identical,
+           "verify": "one layer built identically on every rank (seeded device generator): gathered head outputs of the "
+                     "sharded launches against one launch over all 64 / 8 heads on rank 0 (bound 1e-2)",
+           "devices": devices, "distinct_devices": len(set(ids)),
+           "ms_allgather_per_layer": round(max(t_gather - t_attn, 0.0) / MODEL_L * 1e3, 4),
+           "ms_permute_per_layer": round(max(t_full - t_gather, 0.0) / MODEL_L * 1e3, 4),
+           "workload": f"Qwen3-32B attention shapes, decode batch {B}, ctx {CTX}, block {BS}, {MODEL_L} launches per step "
+                       f"over {L} distinct layer caches, kv heads sharded {H_KV}/{world} per GPU, RCCL all-gather of o per layer",
+           "ms_per_layer_attn_only": round(t_attn / MODEL_L * 1e3, 4),
+           "ms_per_layer_with_allgather": round(t_full / MODEL_L * 1e3, 4),
+           "ms_per_step_64_layers": round(t_full * 1e3, 3),
+           "attn_GBps_all_gpus": round(bytes_layer_all * MODEL_L / t_full / 1e9, 1),
+           "allgather_bytes_per_layer": B * H_Q * D * 2,
+           "tok_per_s_attention_path": round(B / t_full, 1)}
+    if rank == 0 and not verified:
+        rec["error"] = f"gathered head outputs differ from the all-heads launch by {max_diff}"
+    return rec
+
+
+def dp_config5_bench(args, dev, rank, world, dist):
+    """BASELINE config 5 as data-parallel replicas: every rank decodes its own batch of 8 sequences x 32768
+    cached tokens at Llama-3.1-8B attention shapes (32 query / 8 kv heads x 128, block 256), no collective on
+    the data path; value = bytes of all ranks / max time over ranks.  Two layer caches are cycled (1 GiB
+    each), 32 launches (the model's layers) per step."""
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    B, ctx, H_q, H_kv, D, bs, L, MODEL_L = 8, 32768, 32, 8, 128, 256, 2, 32
+    NB, width, bt, cu_k = _paged_layout([ctx] * B, bs, 100 + rank, dev)
+    caches = [(torch.randn(NB, bs, H_kv, D, device=dev).bfloat16(), torch.randn(NB, bs, H_kv, D, device=dev).bfloat16())
+              for _ in range(L)]
+    q = torch.randn(B, H_q, D, device=dev).bfloat16()
+    o = torch.empty_like(q)
+    cu_q = torch.arange(B + 1, dtype=torch.int32, device=dev)
+    ws = torch.empty(max(16, dll.nv_attn_decode_workspace_bytes(B, H_q, H_kv, D, ctx)), dtype=torch.uint8, device=dev)
+
+    def step():
+        for i in range(MODEL_L):
+            kc, vc = caches[i % L]
+            rc = dll.nv_attn_decode_paged(q.data_ptr(), kc.data_ptr(), vc.data_ptr(), o.data_ptr(), cu_q.data_ptr(),
+                                          cu_k.data_ptr(), bt.data_ptr(), B, width, ctx, H_q, H_kv, D, NB, bs, D ** -0.5,
+                                          q.stride(0), o.stride(0), ws.data_ptr(), ws.numel(), stream)
+            if rc != 0:
+                _lib.check(rc, "nv_attn_decode_paged")
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    steps = max(2, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    t = reduce_scalar(dist, dev, time.perf_counter() - t0, "max") / steps
+    finite = bool(torch.isfinite(o.float()).all())
+    nbytes = B * (2 * ctx * H_kv * D * 2 + 2 * H_q * D * 2 + 4 * math.ceil(ctx / bs) + 8) * MODEL_L
+    total = reduce_scalar(dist, dev, float(nbytes), "sum")
+    del caches
+    torch.cuda.empty_cache()
+    return {"workload": f"config 5: {world} replica(s) x batch {B} x ctx {ctx}, H {H_q}/{H_kv}, block {bs}, "
+                        f"{MODEL_L} decode-attention launches per step over {L} layer caches",
+            "replicas": world, "ms_per_step": round(t * 1e3, 3), "attn_GBps_all_gpus": round(total / t / 1e9, 1),
+            "frac_of_hbm_peak_per_gpu": round(total / t / 1e9 / world / HBM_PEAK_GBPS, 4),
+            "tok_per_s_attention_path": round(B * world / t, 1), "outputs_finite": finite}
 
 
 def main():
@@ -555,6 +673,7 @@ def main():
             return {"error": f"{type(e).__name__}: {e}"}
 
     tp = None if args.no_tp else guarded(tp_bench, args, dev, rank, world, dist)
+    dp5 = None if args.no_tp else guarded(dp_config5_bench, args, dev, rank, world, dist)
 
     extra_prefill = extra_cfg = ceiling = None
     if rank == 0 and not args.no_prefill:
@@ -617,6 +736,8 @@ def main():
             out["decode_by_config"] = extra_cfg
         if tp is not None:
             out["head_sharded"] = tp
+        if dp5 is not None:
+            out["dp_config5"] = dp5
         if want_cpu:
             out["cpu_baseline"] = cpu_baseline(w, cpu_kv[0], cpu_kv[1], args.cpu_seconds)
             out["cpu_baseline"]["other_kernels"] = cpu_baseline_other()

@@ -22,6 +22,25 @@ from .. import ops
 from ..utils.cache_context import get_context
 
 
+def _derive_hints(ctx) -> None:
+    """A caller that gave no hints (the reference's runner builds its context from host lists and passes
+    only the tensors): read the two cumulative-length tensors back ONCE per step -- one small device-to-host
+    copy in the first layer of a step that mixes decode rows and prompt chunks; pure decode steps never get
+    here -- and keep the result on the context object, which every layer of the step shares.  Without it
+    each of the step's layers would launch both attention kernels over all sequences."""
+    cu = torch.stack([ctx.cu_seqlens_q, ctx.cu_seqlens_k]).cpu()
+    n_q = (cu[0, 1:] - cu[0, :-1]).tolist()
+    n_k = (cu[1, 1:] - cu[1, :-1]).tolist()
+    nd = 0
+    while nd < len(n_q) and n_q[nd] == 1:
+        nd += 1
+    ctx.num_leading_decode = nd
+    ctx.max_seqlen_k_decode = max(n_k[:nd], default=0)
+    ctx.max_seqlen_q_rest = max(n_q[nd:], default=0)
+    ctx.max_seqlen_k_rest = max(n_k[nd:], default=0)
+    ctx.num_decode_seqs = sum(1 for n in n_q if n == 1)
+
+
 class Attention(nn.Module):
     """q: [T, H_q, D], k/v: [T, H_kv, D] (flattened "super sequence"), returns [T, H_q, D]."""
 
@@ -56,6 +75,8 @@ class Attention(nn.Module):
             return ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k,
                                          ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
                                          cu_seqlens_q=ctx.cu_seqlens_q)
+        if ctx.num_leading_decode is None and ctx.num_decode_seqs is None:
+            _derive_hints(ctx)
         nd = ctx.num_leading_decode
         if nd is not None:
             # decode rows lead the batch: each kernel gets exactly its own sequences (no idle

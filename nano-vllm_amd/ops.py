@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 _BF16 = torch.bfloat16
-_workspaces: dict[int, torch.Tensor] = {}
+_workspaces: dict[tuple[int, int], torch.Tensor] = {}
 _retired: list[torch.Tensor] = []   # outgrown workspaces stay alive: captured graphs may point at them
 
 
@@ -42,13 +42,18 @@ def _rows_ok(t: torch.Tensor, name: str) -> None:
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Split-key scratch of the attention launches: one buffer per (device, stream), so launches on different
+    streams of one device never share partial states (launches on one stream are ordered)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ws = _workspaces.get(idx)
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         if ws is not None:
             _retired.append(ws)
-        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _workspaces[idx] = ws
+        # the first buffer of a device is sized for the usual launches; side streams get what they ask for
+        floor = (64 << 20) if not any(k[0] == idx for k in _workspaces) else (1 << 20)
+        ws = torch.empty(max(nbytes, floor), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
     return ws
 
 

@@ -74,6 +74,22 @@ def test_context_contract():
     nanovllm_amd.set_context(None)
 
 
+def test_hints_are_derived_once_from_the_reference_context_fields():
+    """A context as the reference's runner builds it (nanovllm/engine/model_runner.py:102-111: tensors and
+    the two maxima, no hints): the attention layer derives which leading sequences are decode rows and the
+    per-kernel bounds from cu_seqlens_q / cu_seqlens_k, and keeps them on the context for the step's other layers."""
+    from nanovllm_amd.layers.attention import _derive_hints
+    i32 = lambda xs: torch.tensor(xs, dtype=torch.int32)
+    ctx = nanovllm_amd.CacheContext(cu_seqlens_q=i32([0, 1, 2, 132, 133, 645]), cu_seqlens_k=i32([0, 300, 317, 447, 1447, 2471]),
+                                    max_seqlen_q=512, max_seqlen_k=1024)
+    _derive_hints(ctx)
+    assert ctx.num_leading_decode == 2 and ctx.num_decode_seqs == 3
+    assert ctx.max_seqlen_k_decode == 300 and ctx.max_seqlen_q_rest == 512 and ctx.max_seqlen_k_rest == 1024
+    ctx = nanovllm_amd.CacheContext(cu_seqlens_q=i32([0, 7, 8]), cu_seqlens_k=i32([0, 7, 40]), max_seqlen_q=7, max_seqlen_k=33)
+    _derive_hints(ctx)
+    assert ctx.num_leading_decode == 0 and ctx.max_seqlen_k_decode == 0 and ctx.max_seqlen_q_rest == 7
+
+
 def test_module_signatures_and_parameters():
     attn = nanovllm_amd.Attention(16, 128, 8, 128 ** -0.5, 4096)
     assert attn.num_queries_per_kv == 2 and attn.k_cache is None and attn.v_cache is None

@@ -41,6 +41,18 @@ def _worker(rank, world, port, H_q, H_kv, result_path):
             tag[:, i] = float(h)
         g = all_gather_heads(tag, shard)
         ok = ok and all(bool((g[:, h] == float(h)).all()) for h in range(H_q))
+        # persistent buffers: a step with more tokens than any before makes them grow, and the outgrown
+        # pair stays alive (decode graphs captured earlier replay their gather at the old addresses)
+        from nanovllm_amd.parallel import HeadGather
+        hg = HeadGather(shard)
+        small = hg(tag)
+        old_staging, old_out = hg._staging, hg._out
+        big = hg(tag.repeat(5, 1, 1))
+        ok = ok and hg._staging is not old_staging and any(t is old_staging for t in hg._retired) \
+            and any(t is old_out for t in hg._retired)
+        ok = ok and all(bool((big[:, h] == float(h)).all()) for h in range(H_q)) and small.shape[0] == 3
+        again = hg(tag)                                   # a smaller step reuses the grown buffers
+        ok = ok and hg._staging.shape[0] == 5 * 3 * world and len(hg._retired) == 2 and bool((again == g).all())
         flags = [torch.zeros(1) for _ in range(world)]
         dist.all_gather(flags, torch.tensor([1.0 if ok else 0.0]))
         if rank == 0:

@@ -164,6 +164,7 @@ def k_reads(slot):
     return out
 
 
+PKMUL = os.environ.get("PF_PKMUL", "0") == "1"   # experiment: the two multiplies of a value pair as one v_pk_mul_f32
 EXACT = os.environ.get("PF_EXACT", "1") != "0"   # fp32 score scaling (one multiply per score); 0: all of c in bf16 Q
 N_P2 = int(os.environ.get("PF_NP2", "11"))   # value pairs of key block 0 whose exp stream runs in phase 2
 N_B = int(os.environ.get("PF_NB", "18"))     # entries of that stream that run beside MFMAs 10..15
@@ -191,8 +192,13 @@ def flatten_pairs(pairs):
     exponential in the instruction after it; in exact mode the multiplies of the NEXT pair sit behind the
     exponentials of this one."""
     out = []
+    if PKMUL:
+        def pk(pr):
+            ra = int(pr[5].split()[1].rstrip(",")[1:])
+            return f"v_pk_mul_f32 v[{ra}:{ra + 1}], v[{ra}:{ra + 1}], s[58:59]"
+        pairs = [p_[:5] + (pk(p_), None) for p_ in pairs]
     if pairs and EXACT:
-        out += [pairs[0][5], pairs[0][6]]
+        out += [x for x in (pairs[0][5], pairs[0][6]) if x]
     for n, (ea, eb, aa, ab, cv, ma, mb) in enumerate(pairs):
         out.append(ea)
         if EXACT and n + 1 < len(pairs):
@@ -200,7 +206,7 @@ def flatten_pairs(pairs):
         if n > 0:
             out.append(pairs[n - 1][2])
         out.append(eb)
-        if EXACT and n + 1 < len(pairs):
+        if EXACT and n + 1 < len(pairs) and pairs[n + 1][6]:
             out.append(pairs[n + 1][6])
         if n > 0:
             out.append(pairs[n - 1][3])
@@ -592,6 +598,9 @@ def gen_setup(o: Out):
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_nop 1")
     o.e(f"v_readfirstlane_b32 s{S_R}, v{T[0]}")
+    if PKMUL:
+        o.e(f"v_readfirstlane_b32 s58, v{T[0]}")
+        o.e(f"v_readfirstlane_b32 s59, v{T[0]}")
     lane_consts(o)
     q_fetch(o, S_RW0, K(0, 0))
     if EXIT_AT == "setup":
