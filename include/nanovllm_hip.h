@@ -115,7 +115,11 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  * shares that GPU's array: calls that overlap in time on one GPU (different streams) race; calls on
  * one stream are ordered and safe.  nv_attn_decode_static_scratch_bytes() returns the capacity and
  * resolves the array's address on the current device (-1 on failure); calling it once per device
- * before a graph capture keeps that lookup out of the capture.
+ * before a graph capture keeps that lookup out of the capture.  The array belongs to the CURRENT device:
+ * a stream of another device is refused with NV_ERR_INVALID_ARG.  Launches with at most 8 (sequence, kv
+ * head) pairs combine their key chunks inside the launch here (no second kernel), since the array's
+ * arrival counters are known to be zero; results then agree with nv_attn_decode_paged's to fp32
+ * summation order.
  */
 NV_API int64_t nv_attn_decode_static_scratch_bytes(void);
 NV_API int nv_attn_decode_paged_static(const void* q, const void* k_cache, const void* v_cache, void* o,

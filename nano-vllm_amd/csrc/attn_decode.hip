@@ -930,7 +930,11 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         // states end the launch later than a 16-block merge kernel does).  A caller's workspace may hold
         // anything, so its counters are zeroed on the stream ahead of the launch.
         const int64_t ticket_bytes = ((int64_t)B * H_kv * (int64_t)sizeof(int) + 15) / 16 * 16;
-        single = tuning().decode_single_launch == 1 && ticket_bytes <= kTicketRegion;
+        // On the library's own scratch (counters known to be zero, no memset on the stream) the in-launch combine
+        // is also the default for launches with at most 8 (sequence, kv head) pairs, the one case where it
+        // measured ahead of the second launch (1 sequence x 32 k keys x 8 kv heads: 31.7 - 32.0 against 32.2 - 33.0 us).
+        const int sl = tuning().decode_single_launch;
+        single = (sl == 1 || (sl < 0 && library_workspace && (int64_t)B * H_kv <= 8)) && ticket_bytes <= kTicketRegion;
         if (single) {
             p.tickets = static_cast<int*>(workspace);
             if (!library_workspace) {
@@ -1070,6 +1074,15 @@ extern "C" int nv_attn_decode_paged_static(const void* q, const void* k_cache, c
                "nv_attn_decode_paged_static: this launch needs %lld bytes of split-key partial states, the "
                "built-in scratch holds %lld; use nv_attn_decode_paged with a caller workspace",
                (long long)need, (long long)kStaticScratchBytes);
+    // The scratch address is resolved for the CURRENT device: a stream of another device would make the kernels
+    // of that device write through this device's address.
+    if (stream) {
+        int cur = -1, sdev = -1;
+        if (hipGetDevice(&cur) == hipSuccess && hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess)
+            NV_REQUIRE(cur == sdev, NV_ERR_INVALID_ARG,
+                       "nv_attn_decode_paged_static: the stream belongs to device %d but device %d is current; make "
+                       "the stream's device current before the call", sdev, cur);
+    }
     void* ptr = nullptr;
     const int rc = static_scratch_ptr(&ptr);
     if (rc != NV_OK) return rc;

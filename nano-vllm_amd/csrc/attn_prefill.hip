@@ -428,20 +428,21 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
     prefill_grid(sh, B, H_q, H_kv, max_seqlen_q, 64);
     const int64_t big_wgs = (int64_t)sh.n_pairs * sh.wg_per_pair;
     // with fewer workgroups than CUs it splits the key range like the other kernel does (one workgroup per
-    // CU, at least 8 tiles per split) and leaves unnormalised states for its merge kernel.  Measured on one
-    // 512-query chunk (64 workgroups): from 24 key tiles on three or four splits beat the other kernel,
-    // split or not (1536 keys 27.9 against 32.4 us, 2048 keys 31.2 against 35.4 us); at 16 tiles they do not.
+    // CU, at least 4 tiles per split) and leaves unnormalised states for its merge kernel.  Measured on one
+    // 512-query chunk (64 workgroups), launch pair, this kernel with four key ranges against the other kernel
+    // unsplit: 1024 keys 22.6 against 24.3 us, 1536 keys 25.9 against 34.7, 2048 keys 28.8 against 36.4; at 512
+    // keys (8 tiles) the other kernel wins, 14.7 against 19.5 us.
     int ns_asm = 1;
     if (tn.prefill_split > 0) {
         ns_asm = tn.prefill_split;
     } else if (big_wgs < 256) {
         ns_asm = (int)(256 / big_wgs);
-        if (ns_asm > tiles / 8) ns_asm = tiles / 8;
+        if (ns_asm > tiles / 4) ns_asm = tiles / 4;
         if (ns_asm < 1) ns_asm = 1;
     }
     const bool asm_fills_chip = big_wgs >= 256 || (ns_asm >= 2 && big_wgs * ns_asm >= 128);
     sh.hand_scheduled = tn.prefill_kernel >= 0 ? tn.prefill_kernel == 1
-                                               : (asm_fills_chip && tiles >= (big_wgs >= 256 ? 8 : 24));
+                                               : (asm_fills_chip && tiles >= (big_wgs >= 256 ? 8 : 16));
     if (tiles > prefill_asm_max_tiles()) sh.hand_scheduled = false;
     sh.items_per_wg = 1;
     if (sh.hand_scheduled) {

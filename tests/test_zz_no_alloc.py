@@ -73,6 +73,29 @@ def test_static_scratch_entry_point_matches_workspace_entry_point(single):
     assert need == 16 and torch.equal(o_ws.view(torch.int16), o_st.view(torch.int16))
 
 
+def test_static_scratch_entry_point_combines_small_launches_in_the_launch():
+    """With at most 8 (sequence, kv head) pairs the allocation-free entry point combines the key chunks inside the
+    launch by default (its counters live in the library's scratch: zero at load, put back to zero by every launch),
+    while the workspace entry point runs its merge launch: the two combines sum in different orders, so the outputs
+    agree to a bf16 ulp, and both meet the oracle under the scale-aware row bound.  Three calls in a row (long, short,
+    long) would expose counters that were not reset."""
+    from conftest import assert_rows_close
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    H_q, H_kv, bs = 32, 8, 256
+    for seed, n_ks in ((11, [16384]), (12, [2049]), (13, [9000])):
+        nb = sum((n + bs - 1) // bs for n in n_ks) + 1
+        p = make_paged_problem(seed, [1], n_ks, H_q, H_kv, bs, nb, device=DEV)
+        o_ws, o_st, need = _both(dll, p, H_q, H_kv, bs)
+        assert need > 16                                              # split: partial states and a combine
+        ref = ref_attention.paged_attention_ref(p["q"].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(),
+                                                p["cu_q"].cpu(), p["cu_k"].cpu(), p["block_tables"].cpu(), p["scale"])
+        assert_rows_close(o_st, ref, f"static, in-launch combine, n_k {n_ks}")
+        assert_rows_close(o_ws, ref, f"workspace, merge launch, n_k {n_ks}")
+        diff = (o_st.float() - o_ws.float()).abs()
+        assert (diff <= o_ws.float().abs() * 2 ** -7 + 1e-30).all()
+
+
 def test_static_scratch_entry_point_refuses_oversized_launches():
     from nanovllm_amd import _lib
     dll = _lib.lib()

@@ -8,9 +8,9 @@ mkdir -p $OUT ../../build/variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   objs=""
-  for f in nv_api store_kvcache norm_rope activation attn_decode attn_prefill; do
+  for f in nv_api store_kvcache norm_rope activation attn_decode attn_prefill attn_prefill_asm; do
     o=../../build/variants/${name}_$f.o
-    if [ "$f" = "attn_decode" ] || [ "$f" = "attn_prefill" ] || [ ! -f ../../build/csrc/$f.o ]; then
+    if [ "$f" = "attn_decode" ] || [ ! -f ../../build/csrc/$f.o ]; then
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden $flags -c $f.hip -o $o &
     else
       cp ../../build/csrc/$f.o $o
