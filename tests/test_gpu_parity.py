@@ -596,6 +596,20 @@ def test_prefill_hand_scheduled_kernel_on_engine_step_shapes_with_guard_rows(hip
     assert launches == 100 and bad == 0
 
 
+def test_prefill_key_range_split_on_chunk_shapes_with_guard_rows_and_poisoned_workspace(hip):
+    """The chunks of one long prompt (32 / 8 heads, 64 - 512 queries over 1024 - 8192 cached keys: four key ranges,
+    bf16 states through the workspace, merge launch), 50 launch pairs: the hand-scheduled kernel must agree with the
+    compiler-scheduled one, must not touch the canary rows around the output, and must not read a state that this
+    launch did not write (the workspace holds NaN bit patterns in front of every launch)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import prefill_stress
+    launches, bad = prefill_stress.run(rounds=5, H_q=32, H_kv=8, verbose=False, shapes=prefill_stress.SPLIT_SHAPES,
+                                       poison_workspace=True)
+    assert launches == 50 and bad == 0
+
+
 @pytest.mark.parametrize("kernel", [-1, 0, 1])
 def test_prefill_key_range_split_long_chunk(hip, tuning, kernel):
     """One long sequence prefilled in a chunk: too few workgroups for the chip, so the launch splits

@@ -28,8 +28,19 @@ SHAPES = [
 ]
 
 
-def run(rounds=30, H_q=16, H_kv=8, verbose=True):
-    """Returns (launch pairs, launch pairs whose results or canaries were wrong)."""
+# one or two sequences whose launches have fewer workgroups than CUs: the key range is split, unnormalised states
+# cross a workspace and a merge launch writes the rows (32 / 8 heads: the chunks of one long prompt)
+SPLIT_SHAPES = [
+    ([512], [8192]), ([512], [4096]), ([512], [1024]), ([300], [2049]), ([512], [1536]), ([64], [5000]),
+    ([129], [3000]), ([512, 1], [2560, 77]), ([257], [2048]), ([512], [7777]),
+]
+
+
+def run(rounds=30, H_q=16, H_kv=8, verbose=True, shapes=None, poison_workspace=False):
+    """Returns (launch pairs, launch pairs whose results or canaries were wrong).  poison_workspace fills the
+    split-key scratch with NaN bit patterns in front of every launch: a state that is read without having been
+    written by this launch then shows as NaN rows."""
+    SHAPES = shapes if shapes is not None else globals()["SHAPES"]
     dev = torch.device("cuda", 0)
     D, bs = 128, 256
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -61,6 +72,9 @@ def run(rounds=30, H_q=16, H_kv=8, verbose=True):
                 big = torch.full((guard + T + lead + guard, H_q, D), float("nan"), dtype=torch.bfloat16, device=dev)
                 o = big[guard:guard + T + lead]
                 _lib.set_tuning(prefill_kernel=kern)
+                if poison_workspace:
+                    for ws_ in ops._workspaces.values():
+                        ws_.fill_(0xFF)
                 ops.attn_prefill_varlen(q, kc, vc, cu_q, cu_k, bt, max(n_qs), max(n_ks), D ** -0.5, out=o)
                 outs.append(big)
             _lib.set_tuning()
@@ -115,8 +129,12 @@ def main():
     ap.add_argument("--rounds", type=int, default=30)
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--split", action="store_true", help="the key-range split shapes (32 / 8 heads) with a poisoned workspace")
     args = ap.parse_args()
-    launches, bad = run(args.rounds, args.hq, args.hkv)
+    if args.split:
+        launches, bad = run(args.rounds, 32, 8, shapes=SPLIT_SHAPES, poison_workspace=True)
+    else:
+        launches, bad = run(args.rounds, args.hq, args.hkv)
     print(f"done: {launches} launch pairs, {bad} bad")
 
 
