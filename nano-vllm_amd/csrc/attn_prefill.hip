@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
 #pragma unroll
         for (int s = 0; s < 8; ++s) qf[s] = __builtin_bit_cast(bf16x8, qp[2 * s + h]);
     }
+    // The loop masks raw scores with -inf and takes their maximum before scaling, which needs a positive
+    // scale: a negative one moves its sign into Q (exact), a zero one clears Q and scales by 1 (every visible
+    // score 0, every hidden one still -inf).
+    float scale_log2 = p.scale_log2;
+    if (scale_log2 <= 0.f) {  // uniform, never taken by a softmax scale of 1/sqrt(d)
+        const uint32_t flip = scale_log2 < 0.f ? 0x80008000u : 0u, keep = scale_log2 < 0.f ? ~0u : 0u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint4 w = __builtin_bit_cast(uint4, qf[s]);
+            w.x = (w.x ^ flip) & keep; w.y = (w.y ^ flip) & keep; w.z = (w.z ^ flip) & keep; w.w = (w.w ^ flip) & keep;
+            qf[s] = __builtin_bit_cast(bf16x8, w);
+        }
+        scale_log2 = scale_log2 < 0.f ? -scale_log2 : 1.f;
+    }
 
     f32x16 oacc[4];
 #pragma unroll
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, sacc[0][i]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sacc[1][i]);
-        tmax = max_xor32(tmax) * p.scale_log2;
+        tmax = max_xor32(tmax) * scale_log2;
         if (!__all(tmax <= m_run + kRescaleThreshold)) {  // rare after the first tiles
             const float m_new = fmaxf(m_run, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], p.scale_log2, -m_run));
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], scale_log2, -m_run));
                 sacc[kb][i] = e;
                 psum += e;
             }

@@ -644,6 +644,38 @@ def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit, H_q, H_kv, k
     _attn_check(_run_attention(ops, pd, "mixed"), ref, f"mixed-split{nsplit}")
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("scale", [0.0, -0.0884, 1.0, 0.003, 0.25, 0.0884 * 1.9999])
+def test_prefill_softmax_scale_values(hip, tuning, kernel, scale):
+    """The hand-scheduled kernel splits scale * log2(e) into a power of two (folded into Q, exact) and a factor in
+    [1, 2) applied in fp32: zero (uniform attention over the visible keys), negative, exact powers of two, a factor
+    just below the next power, very peaked and very flat softmax -- chunked, ragged and masked tiles, both kernels."""
+    _, ops = hip
+    n_qs, n_ks = [200, 64, 5, 300], [456, 64, 261, 1100]
+    p = make_paged_problem(41, n_qs, n_ks, 8, 2, 256, 12)
+    p["scale"] = scale
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], scale)
+    tuning(prefill_kernel=kernel)
+    o = _run_attention(ops, to_dev(p), "prefill")
+    _attn_check(o, ref, f"scale {scale} kernel {kernel}")
+    assert_rows_close(o, ref, f"scale {scale} kernel {kernel}", c=0.04)
+
+
+@pytest.mark.parametrize("scale", [0.0, -0.0884, 1.0, 0.003])
+def test_decode_softmax_scale_values(hip, scale):
+    """Decode with zero, negative, large and small softmax scales, short contexts and split ones."""
+    _, ops = hip
+    n_ks = [1, 65, 700, 5000]
+    p = make_paged_problem(43, [1] * 4, n_ks, 16, 8, 256, 30)
+    p["scale"] = scale
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], scale)
+    o = _run_attention(ops, to_dev(p), "decode")
+    _attn_check(o, ref, f"decode scale {scale}")
+    assert_rows_close(o, ref, f"decode scale {scale}", c=0.04)
+
+
 def test_prefill_block_size_64_and_strided_q(hip):
     _, ops = hip
     p = make_paged_problem(77, [100, 260], [164, 260], 8, 2, 64, 9)

@@ -73,8 +73,9 @@ def run(rounds=30, H_q=16, H_kv=8, verbose=True, shapes=None, poison_workspace=F
                 o = big[guard:guard + T + lead]
                 _lib.set_tuning(prefill_kernel=kern)
                 if poison_workspace:
-                    for ws_ in ops._workspaces.values():
-                        ws_.fill_(0xFF)
+                    with torch.inference_mode():             # the buffers may have been made under it
+                        for ws_ in ops._workspaces.values():
+                            ws_.fill_(0xFF)
                 ops.attn_prefill_varlen(q, kc, vc, cu_q, cu_k, bt, max(n_qs), max(n_ks), D ** -0.5, out=o)
                 outs.append(big)
             _lib.set_tuning()
