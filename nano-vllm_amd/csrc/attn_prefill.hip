@@ -572,6 +572,12 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.tiles_per_split = sh.tiles_per_split;
     p.grid_base = (int)sh.grid_base;
     p.pair_items = sh.items_per_wg;
+    p.groups = sh.wg_per_pair / sh.n_qtiles;
+    p.fd_wg_per_pair = make_fastdiv((uint32_t)sh.wg_per_pair);
+    p.fd_groups = make_fastdiv((uint32_t)p.groups);
+    p.fd_H_kv = make_fastdiv((uint32_t)H_kv);
+    p.fd_hpw = make_fastdiv((uint32_t)sh.hpw);
+    p.fd_rows_per_wg = make_fastdiv((uint32_t)sh.rows_per_wg);
     if (sh.nsplit > 1) {
         const int64_t need = sh.hand_scheduled
                                  ? prefill_asm_state_bytes(sh.grid_base, sh.nsplit)

@@ -43,6 +43,9 @@ struct PrefillParams {
     int tiles_per_split;  // 64-key tiles per split
     int grid_base;        // workgroups per split (multiple of 8)
     int pair_items;       // hand-scheduled kernel: query tiles per workgroup (1, 2 or 4; balanced over the sequence)
+    // the block-index decomposition's divisors, prepared by the host (the merge launch is a few hundred instructions long)
+    int groups;           // wg_per_pair / n_qtiles: head groups per kv head (G / hpw)
+    FastDiv fd_wg_per_pair, fd_groups, fd_H_kv, fd_hpw, fd_rows_per_wg;
 };
 
 // hand-scheduled kernel for large launches (attn_prefill_asm.hip): one wave per SIMD, 64 query rows per wave

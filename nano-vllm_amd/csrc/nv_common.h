@@ -40,6 +40,24 @@ inline int check_launch(const char* what) {
     return NV_OK;
 }
 
+// ---- division by a launch constant -------------------------------------------------
+// n / d for 0 <= n < 2^31 and 1 <= d < 2^31 as one 32 x 32 -> 64-bit multiply and a shift (the host picks
+// shr = 31 + ceil(log2 d) and mul = ceil(2^shr / d) < 2^32; the product's error n * (mul * d - 2^shr) stays
+// below 2^shr, so the quotient is exact).  A kernel that decomposes its block index by launch constants pays
+// about 25 instructions per division otherwise, which is most of a short kernel's instruction count.
+struct FastDiv {
+    uint32_t mul, shr;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    FastDiv f;
+    f.shr = 31 + l;
+    f.mul = (uint32_t)(((1ull << f.shr) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv f) { return (uint32_t)(((uint64_t)n * f.mul) >> f.shr); }
+
 // ---- bf16 <-> f32 bit helpers ----------------------------------------------------
 // A uint32 holds two bf16: element 0 in the low half, element 1 in the high half.
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
