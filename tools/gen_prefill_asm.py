@@ -7,7 +7,7 @@ The output is ONE inline-asm body (a C++ raw string) used by csrc/attn_prefill_a
 query rows (two 32-row blocks qb) of one query head and the whole 512-entry register file:
 
   AGPR  a[0:127]    O^T accumulators   O(qb, d, i)   = 64 qb + 16 d + i        (d = 32-dim block)
-        a[128:191]  Q fragments        Q(qb, s, w)   = 128 + 32 qb + 4 s + w   (s = 16-dim k-step), PRE-SCALED
+        a[128:191]  Q fragments        Q(qb, s, w)   = 128 + 32 qb + 4 s + w   (s = 16-dim k-step)
         a[192:255]  K fragments        K(kb, s, w)   = 192 + 32 kb + 4 s + w   (kb = 32-key block)
   VGPR  v[0:127]    S^T, two tiles     S(buf, kb, qb, i) = 64 buf + 32 kb + 16 qb + i
         v[128:159]  V^T fragments      V(d, ks, w)   = 128 + 16 (ks & 1) + 4 d + w   (two of the four k-steps)
@@ -15,15 +15,17 @@ query rows (two 32-row blocks qb) of one query head and the whole 512-entry regi
         v[192:223]  P^T fragments      P(ks, qb, w)  = 192 + 8 ks + 4 qb + w
         v[224:255]  softmax state, lane-constant addresses, temporaries
 
-Softmax scaling: c = scale * log2(e) is split into c = 2^e * r with 1 <= r < 2.  The Q fragments are multiplied
-by 2^e once per item (exact in bf16: no rounding is added to the scores, which stay the fp32 sums of exact bf16
-products that flash-attn's fp32 scaling sees), every S^T accumulator chain STARTS from the block that holds minus
-the running maximum of its query rows (the MFMA's C operand, in the same 2^e units), so an accumulator is already
-2^e * q.k - m, and the probability is exp2(r * accumulator): one v_mul_f32 per score in the exp stream (PF_EXACT=1,
-the default).  PF_EXACT=0 folds all of c into the bf16 Q fragments instead and drops that multiply: 6 - 8 % faster,
-but the rounding of c * q to bf16 perturbs every score by about 2^-9 of its magnitude, which shows on peaked
-softmax rows.  The running maximum is raised (rarely: when a tile maximum exceeds it by more than 2^8) in a side
-path that also shifts the tile's accumulators and the -m blocks.
+Softmax scaling: the Q fragments are used as they are (a score is the fp32 sum of exact bf16 products, which is
+what flash-attn's fp32 scaling sees), every S^T accumulator chain STARTS from the block that holds minus the
+running maximum of its query rows (the MFMA's C operand, in raw score units), so an accumulator is already
+q.k - m, and the probability is exp2(c * accumulator) with c = scale * log2(e): one v_mul_f32 per score in the exp
+stream (PF_EXACT=1, the default).  A scale that is zero or negative reaches the loop as c = 1 or |c| and a factor
+0 or -1 on the Q fragments, applied in a side path of the item's set-up that a positive scale never enters.
+PF_EXACT=0 (timing only since the kernel's set-up passes the factors of the exact form) multiplies all of c into
+the bf16 Q fragments instead and drops the multiply: 4 - 8 % faster, but the rounding of c * q to bf16 perturbs
+every score by about 2^-9 of its magnitude, which shows on peaked softmax rows.  The running maximum is raised
+(rarely: when a tile maximum exceeds it by more than 8 / c, i.e. 2^8 in the exponent) in a side path that also
+shifts the tile's accumulators and the -m blocks.
 
 Tile j (64 keys) is processed by a two-phase software pipeline; iteration j of the loop is
   phase 1: 32 MFMAs  S(j) = K(j) Q^T - m   beside  the rest of exp / row sums / bf16 packing of S(j-1),
@@ -77,7 +79,8 @@ S_QSTR, S_OSTR, S_NQ1 = 76, 77, 78        # token strides in bytes, n_q - 1
 S_ITEMBASE, S_RW0, S_ROWS = 79, 80, 81    # per item: rw0 + shift, first row of the wave, rows that exist
 S_SAVE = 82                    # s[82:83] saved exec
 S_LAST = 84                    # index of the next item while an epilogue prefetches for it
-S_R = 85                       # r = scale * log2(e) / 2^e, 1 <= r < 2 (fp32 bits): the exp stream's multiplier
+S_R = 85                       # c = |scale * log2(e)| (fp32 bits; 1 for scale 0): the exp stream's multiplier
+S_THR = 58                     # 8 / c: a tile maximum this far above the running maximum sends the wave to the side path
 
 # LDS layout (bytes)
 SLOT = 32768                   # one K tile (16 KiB) + one V tile (16 KiB)
@@ -164,7 +167,6 @@ def k_reads(slot):
     return out
 
 
-PKMUL = os.environ.get("PF_PKMUL", "0") == "1"   # experiment: the two multiplies of a value pair as one v_pk_mul_f32
 EXACT = os.environ.get("PF_EXACT", "1") != "0"   # fp32 score scaling (one multiply per score); 0: all of c in bf16 Q
 N_P2 = int(os.environ.get("PF_NP2", "11"))   # value pairs of key block 0 whose exp stream runs in phase 2
 N_B = int(os.environ.get("PF_NB", "18"))     # entries of that stream that run beside MFMAs 10..15
@@ -173,7 +175,7 @@ P1_DMA, P1_VR = (int(x) for x in os.environ.get("PF_P1MIX", "3,4").split(","))  
 
 def exp_pairs(buf, kb):
     """Per value pair of the S registers of key block kb: (exp a, exp b, add a, add b, cvt, mul a, mul b).  The
-    accumulators hold 2^e * q.k - m; the multiplies (exact mode) bring them to scale * log2(e) * q.k - r m."""
+    accumulators hold q.k - m; the multiplies (exact mode) bring them to scale * log2(e) * (q.k - m)."""
     pairs = []
     for qb in range(2):
         for i in range(0, 16, 2):
@@ -192,11 +194,6 @@ def flatten_pairs(pairs):
     exponential in the instruction after it; in exact mode the multiplies of the NEXT pair sit behind the
     exponentials of this one."""
     out = []
-    if PKMUL:
-        def pk(pr):
-            ra = int(pr[5].split()[1].rstrip(",")[1:])
-            return f"v_pk_mul_f32 v[{ra}:{ra + 1}], v[{ra}:{ra + 1}], s[58:59]"
-        pairs = [p_[:5] + (pk(p_), None) for p_ in pairs]
     if pairs and EXACT:
         out += [x for x in (pairs[0][5], pairs[0][6]) if x]
     for n, (ea, eb, aa, ab, cv, ma, mb) in enumerate(pairs):
@@ -416,10 +413,10 @@ def table_lookup(o_list, tile_off_bytes_K, tile_off_bytes_V):
 
 def slow_max(o: Out, buf, tag):
     """Decision of the deferred rescale.  The tile maxima are relative to the running maxima already: any row
-    above 2^8 sends the wave through the side path, which raises the maxima of all rows by max(tile maximum, 0):
+    above 8 / c sends the wave through the side path, which raises the maxima of all rows by max(tile maximum, 0):
     shifts the tile's accumulators and the -m blocks, records the factors and rescales the row sums."""
     o.e(f"v_max_f32 v{T[0]}, v{TM[0]}, v{TM[1]}")
-    o.e(f"v_cmp_lt_f32 vcc, {EIGHT}, v{T[0]}")
+    o.e(f"v_cmp_lt_f32 vcc, s{S_THR}, v{T[0]}" if EXACT else f"v_cmp_lt_f32 vcc, {EIGHT}, v{T[0]}")
     o.e(f"s_cbranch_vccnz .Lpf_slow_{tag}")
     o.label(f".Lpf_slow_{tag}_ret")
     blk = [f".Lpf_slow_{tag}:"]
@@ -427,7 +424,7 @@ def slow_max(o: Out, buf, tag):
         blk.append(f"  v_max_f32 v{T[qb]}, 0, v{TM[qb]}")
     if EXACT:
         for qb in range(2):
-            blk.append(f"  v_mul_f32 v{AL[qb]}, s{S_R}, v{T[qb]}")      # the maxima are in 2^e units: r * shift
+            blk.append(f"  v_mul_f32 v{AL[qb]}, s{S_R}, v{T[qb]}")      # the maxima are raw scores: c * shift
         for qb in range(2):
             blk.append(f"  v_exp_f32 v{AL[qb]}, -v{AL[qb]}")
     else:
@@ -593,14 +590,13 @@ def gen_setup(o: Out):
     o.e(f"v_mov_b32 v{NINF}, 0xff800000")
     o.c("first item: its descriptor; its Q fragments travel to the K fragment registers (scaled into place later)")
     read_descriptor(o, S_ITEM)
-    o.c("word 5 of the first descriptor: r (the operand list is as long as the free scalar registers allow)")
+    o.c("words 5, 6 of the first descriptor: c and 8 / c (the operand list is as long as the asm statement allows)")
     o.e(f"ds_read_b32 v{T[0]}, v{T[5]} offset:20")
+    o.e(f"ds_read_b32 v{T[1]}, v{T[5]} offset:24")
     o.e("s_waitcnt lgkmcnt(0)")
     o.e("s_nop 1")
     o.e(f"v_readfirstlane_b32 s{S_R}, v{T[0]}")
-    if PKMUL:
-        o.e(f"v_readfirstlane_b32 s58, v{T[0]}")
-        o.e(f"v_readfirstlane_b32 s59, v{T[0]}")
+    o.e(f"v_readfirstlane_b32 s{S_THR}, v{T[1]}")
     lane_consts(o)
     q_fetch(o, S_RW0, K(0, 0))
     if EXIT_AT == "setup":
@@ -609,24 +605,37 @@ def gen_setup(o: Out):
 
 
 def q_prescale(o: Out):
-    """Q fragments (bf16 pairs) from the K fragment registers, times scale * log2(e), to their own registers."""
+    """Q fragments (bf16 pairs) from the K fragment registers, where the item's fetch put them while the item
+    before still used the Q registers, to their own registers: a plain move for the factor 1 (any positive
+    softmax scale in exact mode), else times the factor in s_c on a side path."""
     tmp = [T[0], T[1], T[2], T[3]]
+    scaled = []
     for i0 in range(0, 64, 2):
         for k in range(2):
-            o.e(f"v_accvgpr_read_b32 v{tmp[2 * k]}, a{K(0, 0) + i0 + k}")
-        o.e("s_nop 0")
+            scaled.append(f"v_accvgpr_read_b32 v{tmp[2 * k]}, a{K(0, 0) + i0 + k}")
+        scaled.append("s_nop 0")
         for k in range(2):
-            o.e(f"v_lshlrev_b32 v{tmp[2 * k + 1]}, 16, v{tmp[2 * k]}")
+            scaled.append(f"v_lshlrev_b32 v{tmp[2 * k + 1]}, 16, v{tmp[2 * k]}")
         for k in range(2):
-            o.e(f"v_and_b32 v{tmp[2 * k]}, 0xffff0000, v{tmp[2 * k]}")
+            scaled.append(f"v_and_b32 v{tmp[2 * k]}, 0xffff0000, v{tmp[2 * k]}")
         for k in range(2):
-            o.e(f"v_mul_f32 v{tmp[2 * k + 1]}, s{S_C}, v{tmp[2 * k + 1]}")
-            o.e(f"v_mul_f32 v{tmp[2 * k]}, s{S_C}, v{tmp[2 * k]}")
+            scaled.append(f"v_mul_f32 v{tmp[2 * k + 1]}, s{S_C}, v{tmp[2 * k + 1]}")
+            scaled.append(f"v_mul_f32 v{tmp[2 * k]}, s{S_C}, v{tmp[2 * k]}")
         for k in range(2):
-            o.e(f"v_cvt_pk_bf16_f32 v{tmp[2 * k]}, v{tmp[2 * k + 1]}, v{tmp[2 * k]}")
-        o.e("s_nop 0")
+            scaled.append(f"v_cvt_pk_bf16_f32 v{tmp[2 * k]}, v{tmp[2 * k + 1]}, v{tmp[2 * k]}")
+        scaled.append("s_nop 0")
         for k in range(2):
-            o.e(f"v_accvgpr_write_b32 a{Q(0, 0) + i0 + k}, v{tmp[2 * k]}")
+            scaled.append(f"v_accvgpr_write_b32 a{Q(0, 0) + i0 + k}, v{tmp[2 * k]}")
+    if not EXACT:
+        for ln in scaled:
+            o.e(ln)
+        return
+    o.e(f"s_cmp_lg_u32 s{S_C}, 0x3f800000")
+    o.e("s_cbranch_scc1 .Lpf_qscale")
+    for i in range(64):
+        o.e(f"v_accvgpr_mov_b32 a{Q(0, 0) + i}, a{K(0, 0) + i}")
+    o.label(".Lpf_qscale_ret")
+    _ool.append([".Lpf_qscale:"] + ["  " + ln for ln in scaled] + ["  s_branch .Lpf_qscale_ret"])
 
 
 def gen_item_prologue(o: Out):
