@@ -780,6 +780,42 @@ def test_full_size_decode_properties(hip, peaked):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("path", ["decode", "decode_g8", "prefill0", "prefill1", "chunk0", "chunk1"])
+def test_full_size_power_of_two_equivariance(hip, tuning, path):
+    """Size-independent and BIT-EXACT at the benchmark sizes: powers of two commute with every rounding on the
+    path (bf16 inputs, fp32 products and sums, bf16 states and outputs), so (1) V x 2 doubles the output exactly,
+    (2) q x 2 with scale / 2 and (3) K x 4 with scale / 4 leave every score, hence every output bit, unchanged.
+    A kernel that rounded a scaled query or score below fp32, mixed up a head or a key range, or normalised with a
+    different sum than it accumulated would break one of them.  Decode at config 2 (B 256, ctx 513..768) and at
+    a G = 8 shard shape, whole-prompt prefill of 8192 tokens and its last 512-token chunk (key-range split), both
+    prefill kernels."""
+    _, ops = hip
+    bs = 256
+    if path.startswith("decode"):
+        H_q, H_kv = (16, 8) if path == "decode" else (16, 2)
+        g = torch.Generator().manual_seed(3)
+        B = 256 if path == "decode" else 64
+        ctx = torch.randint(513, 769, (B,), generator=g).tolist() if path == "decode" else [2048] * B
+        p = make_paged_problem(3, [1] * B, ctx, H_q, H_kv, bs, sum((c + bs - 1) // bs for c in ctx), pad_cols=0)
+        mode = "decode"
+    else:
+        H_q, H_kv, n = 32, 8, 8192
+        p = make_paged_problem(6, [n], [n], H_q, H_kv, bs, n // bs, pad_cols=0)
+        tuning(prefill_kernel=int(path[-1]))
+        mode = "prefill"
+    pd = to_dev(p)
+    if path.startswith("chunk"):
+        pd = dict(pd, q=pd["q"][n - 512:].contiguous(), cu_q=torch.tensor([0, 512], dtype=torch.int32, device=DEV), max_q=512)
+    o = _run_attention(ops, pd, mode)
+    assert torch.isfinite(o.float()).all()
+    o_v2 = _run_attention(ops, dict(pd, v_cache=pd["v_cache"] * 2), mode)
+    assert torch.equal(o_v2, (o.float() * 2).bfloat16()), "V x 2 must double the output exactly"
+    o_q2 = _run_attention(ops, dict(pd, q=pd["q"] * 2, scale=p["scale"] / 2), mode)
+    assert torch.equal(o_q2, o), "q x 2 with scale / 2 must not change a bit"
+    o_k4 = _run_attention(ops, dict(pd, k_cache=pd["k_cache"] * 4, scale=p["scale"] / 4), mode)
+    assert torch.equal(o_k4, o), "K x 4 with scale / 4 must not change a bit"
+
+
 @pytest.mark.parametrize("peaked", [False, True])
 @pytest.mark.parametrize("kernel", [0, 1])
 def test_full_size_prefill_properties(hip, tuning, kernel, peaked):
@@ -789,8 +825,8 @@ def test_full_size_prefill_properties(hip, tuning, kernel, peaked):
     const gives const; (3) a sample of rows x 8 heads against the oracle under that bound, whose sensitivity
     is shown per row (the oracle without one 256-key block violates it), from the whole-prompt launch and
     from the chunk launch; (4) permuting the physical blocks leaves the output bit-identical.  ``peaked``:
-    softmax scale x 4 (a few keys carry the weight, outputs O(1)): the hand-scheduled kernel folds the scale
-    into Q and rounds the product to bf16, which this variant measures."""
+    softmax scale x 4 (a few keys carry the weight, outputs O(1)): any rounding of scaled scores or scaled
+    queries below fp32 shows here first."""
     _, ops = hip
     H_q, H_kv, n, bs, chunk = 32, 8, 8192, 256, 512
     NB = n // bs
