@@ -785,8 +785,9 @@ def test_full_size_power_of_two_equivariance(hip, tuning, path):
     """Size-independent and BIT-EXACT at the benchmark sizes: powers of two commute with every rounding on the
     path (bf16 inputs, fp32 products and sums, bf16 states and outputs), so (1) V x 2 doubles the output exactly,
     (2) q x 2 with scale / 2 and (3) K x 4 with scale / 4 leave every score, hence every output bit, unchanged.
-    A kernel that rounded a scaled query or score below fp32, mixed up a head or a key range, or normalised with a
-    different sum than it accumulated would break one of them.  Decode at config 2 (B 256, ctx 513..768) and at
+    Any step whose result depends on absolute magnitudes breaks one of them: a threshold or clamp kept in the wrong
+    units (the running-maximum thresholds are relative to 1 / scale), an intermediate with a fixed exponent range,
+    a flush of small values.  Decode at config 2 (B 256, ctx 513..768) and at
     a G = 8 shard shape, whole-prompt prefill of 8192 tokens and its last 512-token chunk (key-range split), both
     prefill kernels."""
     _, ops = hip
