@@ -86,6 +86,7 @@ S_THR = 58                     # 8 / c: a tile maximum this far above the runnin
 SLOT = 32768                   # one K tile (16 KiB) + one V tile (16 KiB)
 V_OFF = 16384
 PARAM_OFF = 16384              # per-wave staging area: [16 Q fragments x 1 KiB][16 lane parameters x 256 B]
+FIRST_KV_PIECES = 12           # LDS-DMA instructions per wave of K(0), V(0), K(1), requested behind the first item's Q image
 MFMA = "v_mfma_f32_32x32x16_bf16"
 NEG_BIG = "0xf149f2ca"         # -1.0e30f
 POS_BIG = "0x7149f2ca"         # +1.0e30f
@@ -597,8 +598,15 @@ def gen_setup(o: Out):
     o.e("s_nop 1")
     o.e(f"v_readfirstlane_b32 s{S_R}, v{T[0]}")
     o.e(f"v_readfirstlane_b32 s{S_THR}, v{T[1]}")
-    lane_consts(o)
-    q_fetch(o, S_RW0, K(0, 0))
+    o.c("first item: its Q fragments were requested as one tile image (the K tile layout) into the wave's staging")
+    o.c("area by the code in front of this body, AHEAD of the first K/V tiles: they are read back while those fly")
+    o.e(f"ds_read_b32 v{T[2]}, v{PADDR} offset:{PARAM_OFF + 14 * 256}")
+    o.e(f"ds_read_b32 v{T[3]}, v{PADDR} offset:{PARAM_OFF + 15 * 256}")
+    o.e("s_waitcnt lgkmcnt(0)")
+    o.e(f"s_waitcnt vmcnt({FIRST_KV_PIECES})")
+    for qb in range(2):
+        for sk in range(8):
+            o.e(f"ds_read_b128 {rng('a', K(qb, sk), 4)}, v{T[2 + (sk & 1)]} offset:{8192 * qb + 512 * (sk >> 1)}")
     if EXIT_AT == "setup":
         o.e("s_waitcnt vmcnt(0)")
         o.e("s_branch .Lpf_end")
