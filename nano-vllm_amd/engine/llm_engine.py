@@ -102,7 +102,8 @@ class LLMEngine:
 
     def generate(self, prompts, sampling_params=None):
         """prompts: list of token-id lists (or strings with a tokenizer).  Returns (outputs, metrics);
-        outputs[i] = {"token_ids": [...], "text": str | None, "cached_tokens": prompt tokens taken from the
+        outputs[i] = {"token_ids": [...], "text": str | None, "num_preemptions": times the request's blocks were
+        taken away and its K/V recomputed, "cached_tokens": prompt tokens taken from the
         prefix cache} in prompt order."""
         if not isinstance(sampling_params, (list, tuple)):
             sampling_params = [sampling_params] * len(prompts)
@@ -152,5 +153,6 @@ class LLMEngine:
         outs = []
         for s in seqs:
             text = self.tokenizer.decode(s.output_tokens) if self.tokenizer is not None else None
-            outs.append({"token_ids": list(s.output_tokens), "text": text, "cached_tokens": s.num_cached_tokens})
+            outs.append({"token_ids": list(s.output_tokens), "text": text, "cached_tokens": s.num_cached_tokens,
+                         "num_preemptions": s.num_preemptions})
         return outs, metrics

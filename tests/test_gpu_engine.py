@@ -166,3 +166,31 @@ def test_prefix_cache_hit_gives_the_same_tokens_on_the_hip_path():
     fresh, _ = LLMEngine(model, cfg, **kw).generate([p2], SamplingParams(0.0, 24))
     assert fresh[0]["cached_tokens"] == 0
     assert out[0]["token_ids"] == fresh[0]["token_ids"]
+
+
+@pytest.mark.parametrize("graphs", [False, True])
+def test_preemption_on_the_hip_path(graphs):
+    """Requests that together outgrow the KV cache, on the HIP kernels with pipelined decode (and captured decode
+    graphs): the youngest running sequence is preempted and its K/V recomputed later by the prefill kernel.  Every
+    request finishes with its full token count, all blocks come back, and every request's first token (sampled
+    before any preemption) is the big-cache run's.  Later tokens are not compared: the two runs batch differently
+    (other launch plans and GEMM shapes, i.e. other fp32 summation orders), and a random-init model's greedy
+    tokens flip at numerical ties; exact token equality under preemption is shown on the CPU with the fp32 oracle
+    layers (tests/test_engine_cpu.py)."""
+    cfg = ModelConfig(vocab_size=4096, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                      num_attention_heads=16, num_key_value_heads=8, head_dim=128, max_position_embeddings=4096)
+    model = build(cfg, None, True, seed=9)
+    g = torch.Generator().manual_seed(21)
+    prompts = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in (300, 280, 100, 200)]
+    params = [SamplingParams(0.0, n) for n in (260, 50, 200, 120)]
+    kw = dict(block_size=256, max_num_batched_tokens=600, long_prefill_token_threshold=256, device=DEV, eos=-1,
+              use_graphs=graphs, pipelined_decode=True)
+    want, _ = LLMEngine(model, cfg, num_kvcache_blocks=16, **kw).generate(prompts, params)
+    assert all(o["num_preemptions"] == 0 for o in want)
+    small = LLMEngine(model, cfg, num_kvcache_blocks=5, **kw)      # 1280 tokens of cache for 1510 tokens of requests
+    got, m = small.generate(prompts, params)
+    assert [len(o["token_ids"]) for o in got] == [p.max_tokens for p in params]
+    assert m.num_generated_tokens == sum(p.max_tokens for p in params)
+    assert sum(o["num_preemptions"] for o in got) >= 1
+    assert small.scheduler.block_manager.num_free_blocks == 5
+    assert [o["token_ids"][0] for o in got] == [w["token_ids"][0] for w in want]
