@@ -780,6 +780,22 @@ def test_full_size_decode_properties(hip, peaked):
     assert torch.equal(o, o2)
 
 
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_prefill_chunk_over_more_keys_than_the_hand_scheduled_kernels_tile_table_holds(hip, tuning, kernel):
+    """A 96-token chunk over 70,000 cached keys: more 64-key tiles than the hand-scheduled kernel's table of tile
+    addresses holds (1024), so the launch plan has to take the other kernel even when the hand-scheduled one is
+    forced; key-range split and merge on a context longer than any benchmark's.  Rows under the scale-aware bound."""
+    _, ops = hip
+    n_q, n_k, bs = 96, 70000, 256
+    p = make_paged_problem(13, [n_q], [n_k], 8, 2, bs, (n_k + bs - 1) // bs + 1)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    tuning(prefill_kernel=kernel)
+    o = _run_attention(ops, to_dev(p), "prefill")
+    _attn_check(o, ref, f"70k keys kernel {kernel}")
+    assert_rows_close(o, ref, f"70k keys kernel {kernel}")
+
+
 @pytest.mark.parametrize("path", ["decode", "decode_g8", "prefill0", "prefill1", "chunk0", "chunk1"])
 def test_full_size_power_of_two_equivariance(hip, tuning, path):
     """Size-independent and BIT-EXACT at the benchmark sizes: powers of two commute with every rounding on the
