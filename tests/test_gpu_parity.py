@@ -780,6 +780,19 @@ def test_full_size_decode_properties(hip, peaked):
     assert torch.equal(o, o2)
 
 
+def test_decode_over_150k_keys(hip):
+    """Two sequences x 150,001 and 3 keys (587 blocks; a context longer than any benchmark's, next to a tiny one):
+    many key chunks per (sequence, kv head) and a wide block table.  Rows under the scale-aware bound."""
+    _, ops = hip
+    n_ks, bs = [150001, 3], 256
+    p = make_paged_problem(17, [1, 1], n_ks, 8, 2, bs, sum((n + bs - 1) // bs for n in n_ks) + 1)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    o = _run_attention(ops, to_dev(p), "decode")
+    _attn_check(o, ref, "150k keys")
+    assert_rows_close(o, ref, "150k keys")
+
+
 @pytest.mark.parametrize("kernel", [0, 1])
 def test_prefill_chunk_over_more_keys_than_the_hand_scheduled_kernels_tile_table_holds(hip, tuning, kernel):
     """A 96-token chunk over 70,000 cached keys: more 64-key tiles than the hand-scheduled kernel's table of tile
