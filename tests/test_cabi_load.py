@@ -125,3 +125,35 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="not bound"):
         attn(torch.zeros(1, 4, 128), torch.zeros(1, 2, 128), torch.zeros(1, 2, 128))
     nanovllm_amd.set_context(None)
+
+
+def test_fast_division_by_launch_constants_is_exact():
+    """The kernels take a block index apart with host-prepared divisors (csrc/nv_common.h: make_fastdiv /
+    fast_div): shr = 31 + ceil(log2 d), mul = ceil(2^shr / d), n / d = (n * mul) >> shr.  The same arithmetic
+    restated here must be exact for every 0 <= n < 2^31 that matters: all small divisors exhaustively over small
+    n, and edge values (multiples of d and their neighbours, 2^31 - 1) for small, power-of-two, odd and large
+    divisors; mul must fit 32 bits (the device multiplies 32 x 32 -> 64)."""
+    import random
+
+    def make(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        shr = 31 + l
+        return ((1 << shr) + d - 1) // d, shr
+
+    rnd = random.Random(0)
+    divisors = list(range(1, 300)) + [2 ** k + e for k in range(8, 31) for e in (-1, 0, 1)] + \
+        [rnd.randrange(1, 2 ** 31) for _ in range(200)]
+    for d in divisors:
+        if not 1 <= d < 2 ** 31:
+            continue
+        mul, shr = make(d)
+        assert mul < 2 ** 32 and shr < 64, (d, mul, shr)
+        ns = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 2 ** 31 - 1, 2 ** 31 - d, (2 ** 31 - 1) // d * d,
+              (2 ** 31 - 1) // d * d - 1] + [rnd.randrange(0, 2 ** 31) for _ in range(50)]
+        if d < 300:
+            ns += list(range(0, 4 * d + 2))
+        for n in ns:
+            if 0 <= n < 2 ** 31:
+                assert (n * mul) >> shr == n // d, (n, d)
