@@ -4,7 +4,7 @@ in tests/): random head counts, block sizes, batch compositions (decode rows, ch
 one-token sequences), lengths, softmax scales and query strides; both prefill kernels, the launch plan's choice,
 forced key-range splits, both decode work-item forms and combines.  Output rows sit inside NaN guard rows.
 
-    python tools/fuzz_attention.py --iters 300 [--seed 0]
+    python tests/fuzz_attention.py --iters 300 [--seed 0]
 """
 import argparse
 import os
