@@ -15,7 +15,8 @@ timed region.
 `roofline` is for the dominant kernel (paged decode attention) alone: algorithmic bytes per launch
 (4096 B per cached token + 8 KiB of Q/O + table bytes, summed over the batch) divided by the
 average launch duration measured with HIP events on the launch stream inside the timed steps
-(`attn_kernel_pct_of_hbm_peak` repeats its fraction).
+(event pairs around the attention launches of every 7th layer, the sampled layers moving from step to
+step: a pair around every launch slows the step by 6 %; `attn_kernel_pct_of_hbm_peak` repeats its fraction).
 `prefill` (rank 0): the bf16 MFMA prefill kernel on BASELINE config 3 shapes against the 2.5 PFLOP/s peak.
 `decode_by_config` (rank 0): the decode launch at the per-GPU shapes of configs 4 and 5.
 `cpu_baseline` times the CPU oracle (torch, fp32) of the same attention, and of the scatter / norm /
@@ -159,9 +160,16 @@ class Workload:
         return plan
 
 
-def run_step(plan, events=None):
+def run_step(plan, events=None, phase=0, every=7):
+    """One step.  With `events`, HIP event pairs go around the attention launches of every `every`-th layer,
+    starting at layer `phase % every` (the caller moves `phase` from step to step, so every layer is sampled):
+    a pair around EVERY launch costs the step 6 % (two marker packets per launch: 3.41 against 3.21 ms,
+    tools/step_modes.py), which would be charged to `value`."""
+    layer = 0
     for fn, args, is_attn in plan:
-        if events is not None and is_attn:
+        if is_attn:
+            layer += 1
+        if events is not None and is_attn and (layer - 1 + phase) % every == 0:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             rc = fn(*args)
@@ -647,8 +655,8 @@ def main():
     barrier()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(plan, events)
+    for i in range(args.steps):
+        run_step(plan, events, phase=i, every=min(7, args.layers))
     barrier()
     elapsed = reduce_scalar(dist, dev, time.perf_counter() - t0, "max")
     step_bytes_all = reduce_scalar(dist, dev, float(w.step_bytes(args.attn_only)), "sum")
