@@ -6,9 +6,9 @@
 Workload (N=1): Qwen3-0.6B shapes (L=28, H_q=16, H_kv=8, D=128, hidden 1024), decode batch 256,
 context lengths ragged U[513,768] (the 512-in/256-out run's range), KV block 256, bf16,
 synthetic random data, shuffled physical blocks.  One STEP = one decode step of the hot path
-over all 28 layers: per layer two residual-add RMSNorms at hidden size, the fused q/k-norm +
-rotary + KV-cache scatter, and paged decode attention.  Inputs are resident in HBM before the
-timed region.
+over all 28 layers: per layer two residual-add RMSNorms at hidden size and ONE launch that does the
+q/k-norm, the rotary embedding, the KV-cache scatter and the paged decode attention (`--two-launch`: the
+scatter launch and the attention launch it replaces).  Inputs are resident in HBM before the timed region.
 
 `value` = algorithmic HBM bytes of the whole step / wall time of the step (GB/s);
 `step_pct_of_hbm_peak` is that figure per GPU against 8 TB/s.
@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--attn-only", action="store_true", help="step = decode attention launches only")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="q/k-norm + rotary + scatter as a launch of its own in front of the attention launch")
     ap.add_argument("--tp-layers", type=int, default=8, help="layers in the head-sharded sub-benchmark")
     ap.add_argument("--no-tp", action="store_true", help="skip the head-sharded sub-benchmark")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end generation run (N=1 only)")
@@ -119,18 +121,25 @@ class Workload:
         return sum(2 * c * self.H_KV * self.D * 2 + 2 * self.H_Q * self.D * 2 + 4 * math.ceil(c / self.BS) + 8
                    for c in self.ctx)
 
-    def step_bytes(self, attn_only=False):
+    def step_bytes(self, attn_only=False, one_launch=True):
         a = self.attn_bytes_per_launch()
         if attn_only:
             return a * self.L
         T = self.B
         heads = self.H_Q + 2 * self.H_KV
-        fused = 2 * T * heads * self.D * 2 + T * self.D * 4 + 12 * T        # in + out, cos/sin row, pos + slot
+        if one_launch:
+            # q/k-norm + rotary + scatter inside the attention launch: the raw k, v rows in, the cache rows out,
+            # the cos/sin row, position and slot (the raw q row is the attention's own Q read)
+            fused = 2 * T * 2 * self.H_KV * self.D * 2 + T * self.D * 4 + 12 * T
+        else:
+            fused = 2 * T * heads * self.D * 2 + T * self.D * 4 + 12 * T    # in + out, cos/sin row, pos + slot
         norm = T * self.HIDDEN * 2 * 4 + self.HIDDEN * 2                    # x, res in; y, new_res out; weight
         return (a + fused + 2 * norm) * self.L
 
     # ---- raw C-ABI launch plans (argument tuples prebuilt; nothing allocated per call) ---
-    def build_plan(self, attn_only=False):
+    def build_plan(self, attn_only=False, one_launch=True):
+        """Per layer: add+RMSNorm, then q/k-norm + rotary + KV scatter + paged decode attention as ONE launch
+        (`one_launch`, what the engine's decode step runs) or as the two launches it replaces, then add+RMSNorm."""
         from nanovllm_amd import _lib
         dll = _lib.lib()
         stream = torch.cuda.current_stream(self.dev).cuda_stream
@@ -139,22 +148,33 @@ class Workload:
         plan = []          # (fn, args, is_attention)
         for l in range(self.L):
             kc, vc = self.kv_cache[0, l], self.kv_cache[1, l]
+            norm_args = (self.hidden.data_ptr(), self.resid.data_ptr(), self.h_w.data_ptr(), self.y.data_ptr(),
+                         self.new_res.data_ptr(), self.B, self.HIDDEN, self.EPS, stream)
             if not attn_only:
-                norm_args = (self.hidden.data_ptr(), self.resid.data_ptr(), self.h_w.data_ptr(), self.y.data_ptr(),
-                             self.new_res.data_ptr(), self.B, self.HIDDEN, self.EPS, stream)
                 plan.append((dll.nv_add_rmsnorm, norm_args, False))
-                plan.append((dll.nv_qknorm_rope_store,
+            if one_launch and not attn_only:
+                plan.append((dll.nv_attn_decode_paged_fused,
                              (self.q_in.data_ptr(), self.k_in.data_ptr(), self.v_in.data_ptr(), self.q_w.data_ptr(),
                               self.k_w.data_ptr(), self.cos_sin.data_ptr(), self.positions.data_ptr(),
-                              self.slots.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.q_rot.data_ptr(), None,
-                              self.B, self.H_Q, self.H_KV, self.D, self.MAX_POS, self.EPS, self.NB, self.BS,
-                              self.q_in.stride(0), self.k_in.stride(0), self.v_in.stride(0), stream), False))
-            plan.append((dll.nv_attn_decode_paged,
-                         (self.q_rot.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.o.data_ptr(),
-                          self.cu_q.data_ptr(), self.cu_k.data_ptr(), self.block_tables.data_ptr(), self.B,
-                          self.block_tables.shape[1], self.max_k, self.H_Q, self.H_KV, self.D, self.NB, self.BS,
-                          self.scale, self.q_rot.stride(0), self.o.stride(0), self.ws.data_ptr(), self.ws.numel(),
-                          stream), True))
+                              self.slots.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.o.data_ptr(),
+                              self.cu_k.data_ptr(), self.block_tables.data_ptr(), self.B, self.block_tables.shape[1],
+                              self.max_k, self.H_Q, self.H_KV, self.D, self.NB, self.BS, self.MAX_POS, self.EPS,
+                              self.scale, self.q_in.stride(0), self.k_in.stride(0), self.v_in.stride(0),
+                              self.o.stride(0), self.ws.data_ptr(), self.ws.numel(), stream), True))
+            else:
+                if not attn_only:
+                    plan.append((dll.nv_qknorm_rope_store,
+                                 (self.q_in.data_ptr(), self.k_in.data_ptr(), self.v_in.data_ptr(), self.q_w.data_ptr(),
+                                  self.k_w.data_ptr(), self.cos_sin.data_ptr(), self.positions.data_ptr(),
+                                  self.slots.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.q_rot.data_ptr(), None,
+                                  self.B, self.H_Q, self.H_KV, self.D, self.MAX_POS, self.EPS, self.NB, self.BS,
+                                  self.q_in.stride(0), self.k_in.stride(0), self.v_in.stride(0), stream), False))
+                plan.append((dll.nv_attn_decode_paged,
+                             (self.q_rot.data_ptr(), kc.data_ptr(), vc.data_ptr(), self.o.data_ptr(),
+                              self.cu_q.data_ptr(), self.cu_k.data_ptr(), self.block_tables.data_ptr(), self.B,
+                              self.block_tables.shape[1], self.max_k, self.H_Q, self.H_KV, self.D, self.NB, self.BS,
+                              self.scale, self.q_rot.stride(0), self.o.stride(0), self.ws.data_ptr(), self.ws.numel(),
+                              stream), True))
             if not attn_only:
                 plan.append((dll.nv_add_rmsnorm, norm_args, False))
         return plan
@@ -642,7 +662,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w = Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi, seed=rank)
-    plan = w.build_plan(args.attn_only)
+    one_launch = not args.two_launch and not args.attn_only
+    plan = w.build_plan(args.attn_only, one_launch)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -659,7 +680,7 @@ def main():
         run_step(plan, events, phase=i, every=min(7, args.layers))
     barrier()
     elapsed = reduce_scalar(dist, dev, time.perf_counter() - t0, "max")
-    step_bytes_all = reduce_scalar(dist, dev, float(w.step_bytes(args.attn_only)), "sum")
+    step_bytes_all = reduce_scalar(dist, dev, float(w.step_bytes(args.attn_only, one_launch)), "sum")
 
     ms_per_step = elapsed / args.steps * 1e3
     value = step_bytes_all / (elapsed / args.steps) / 1e9
@@ -722,7 +743,9 @@ def main():
             "config": {"workload": f"Qwen3-0.6B shapes, decode batch {args.batch}, ctx U[{args.ctx_lo},{args.ctx_hi}], "
                                    f"block 256, {args.layers} layers; step = "
                                    + ("decode attention only" if args.attn_only else
-                                      "2x add+RMSNorm, fused qk-norm+RoPE+KV store, paged decode attention per layer"),
+                                      ("2x add+RMSNorm and one launch of qk-norm+RoPE+KV store+paged decode attention per layer"
+                                       if one_launch else
+                                       "2x add+RMSNorm, fused qk-norm+RoPE+KV store, paged decode attention per layer")),
                        "H_q": 16, "H_kv": 8, "head_dim": 128, "batch": args.batch, "layers": args.layers,
                        "parallelism": "single GPU" if world == 1 else f"dp{world} replicas"
                                       + (" (REHEARSAL: ranks share one GPU, gloo)" if share else ""),
@@ -730,7 +753,9 @@ def main():
             "step_pct_of_hbm_peak": round(100 * value / world / HBM_PEAK_GBPS, 2),
             "attn_kernel_pct_of_hbm_peak": round(100 * achieved / HBM_PEAK_GBPS, 2),
             "hot_path_tok_per_s": round(args.batch * world / (ms_per_step * 1e-3), 1),
-            "roofline": {"bound": "hbm", "kernel": "attn_decode_kernel (decode attention launch only, rank 0)",
+            "roofline": {"bound": "hbm", "kernel": ("attn_decode_kernel<FUSE> (the attention launch, which also normalises, rotates and stores "
+                                    "the step's token; priced on the attention's algorithmic bytes alone; rank 0)"
+                                    if one_launch else "attn_decode_kernel (decode attention launch only, rank 0)"),
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(attn_ms, 5),

@@ -217,6 +217,33 @@ NV_API int nv_qknorm_rope_store(const void* q, const void* k, const void* v, con
                          int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
                          void* stream);
 
+/*
+ * A pure decode step's whole attention block in ONE launch: the chain nanovllm/model/qwen3.py:67-75
+ * (q_norm, k_norm, rope), the store at nanovllm/layers/attention.py:230-231 and the flash_attn_varlen_func
+ * call at :241-252 for a step in which every sequence has exactly one new token.  Equal, bit for bit, to
+ * nv_qknorm_rope_store followed by nv_attn_decode_paged on the same inputs (the per-head arithmetic is one
+ * function, and the attention sees the new token's key and value as it would read them back from the cache).
+ *   q, k, v: the step's RAW projections, [B, H_q, D] / [B, H_kv, D] bf16, token strides in elements (slices of
+ *   one fused projection are fine); token b belongs to sequence b.
+ *   q_w, k_w, cos_sin, positions, max_pos, eps: as for nv_qknorm_rope_store.
+ *   slot_mapping: [B] int32, the cache slot of sequence b's new token, i.e. of its key number
+ *   cu_seqlens_k[b+1] - cu_seqlens_k[b] - 1 (the reference's runner builds it that way,
+ *   nanovllm/engine/model_runner.py:71-81); a slot outside the cache is not written, the attention still
+ *   sees the new token.
+ *   k_cache, v_cache: read for keys 0 .. n_k - 2 and WRITTEN at the new token's slot.
+ *   The remaining arguments, the workspace and the results are nv_attn_decode_paged's.
+ * Shapes: H_q / H_kv of 1 or 2 and block sizes that are multiples of 16; NV_ERR_UNSUPPORTED otherwise
+ * (run the two launches then).
+ */
+NV_API int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w,
+                               const void* k_w, const float* cos_sin, const int64_t* positions,
+                               const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
+                               const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
+                               int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
+                               int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
+                               int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                               int64_t o_stride_t, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnanovllm_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -39,6 +39,9 @@ PROTOTYPES = {
     "nv_attn_decode_static_scratch_bytes": (_i64, []),
     "nv_attn_decode_paged_static": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                            _i32, _i64, _i32, _f32, _i64, _i64, _vp]),
+    "nv_attn_decode_paged_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32,
+                                          _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i64, _f32, _f32, _i64, _i64,
+                                          _i64, _i64, _vp, _i64, _vp]),
     "nv_attn_prefill_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "nv_attn_prefill_varlen": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                       _i32, _i32, _i64, _i32, _f32, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),

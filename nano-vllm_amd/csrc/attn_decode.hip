@@ -19,7 +19,7 @@
 // as called at nanovllm/layers/attention.py:241-252 (the query sees every cached key,
 // including the one stored earlier in the same forward, :230-231).
 #include "nv_common.h"
-
+#include "norm_rope_shared.h"
 
 // Build-time tuning knobs (defaults are the measured best on MI355X).
 #ifndef NV_DEC_WAVES
@@ -61,6 +61,12 @@ __device__ __forceinline__ uint4 kv_load(const uint4* p) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// c ? a : b on values (the conditional operator on two uint4 lvalues selects between their ADDRESSES, which
+// keeps both objects in memory instead of registers)
+__device__ __forceinline__ uint4 pick(bool c, const uint4 a, const uint4 b) {
+    return make_uint4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+
 // 16-byte write-through store (sc1): the bytes go to memory instead of staying dirty in this XCD's L2.
 // The trailing s_nop keeps the compiler's next instruction off the data registers until the store has
 // read them.  The compiler does not count this store: drain with an explicit s_waitcnt vmcnt(0).
@@ -84,6 +90,19 @@ struct DecodeParams {
     int64_t num_blocks;
     int64_t q_stride_vec, o_stride_vec;
     float scale_log2;
+    // FUSE instantiations only (nv_attn_decode_paged_fused): q is the RAW query projection, and the step's new
+    // key / value rows arrive as projections too; the kernel normalises and rotates them itself
+    const uint4* k_new;       // [B, H_kv, D] raw key projection of the step's token
+    const uint4* v_new;       // [B, H_kv, D] value projection
+    const uint4* q_w;         // [D] q-norm weight, or null (no q/k-norm)
+    const uint4* k_w;
+    const float4* cos_sin;    // [max_pos, D] fp32: cos | sin
+    const int64_t* positions; // [B]
+    const int32_t* slots;     // [B] cache slot of the new token
+    uint4* k_cache_w;         // the caches again, writable
+    uint4* v_cache_w;
+    int64_t k_stride_vec, v_stride_vec, max_pos, num_slots;
+    float eps;
 };
 
 // Final state of one (sequence, query head, key chunk) held by 16 lanes (lane c: dims 8c..8c+7):
@@ -283,7 +302,14 @@ __device__ __forceinline__ void wg_ticket_merge(const DecodeParams& p, int* flag
 // WGS = false: every wave is its own work item.  WGS = true (launches with few (sequence, head)
 // pairs): the workgroup is one work item, its waves take a quarter of the chunk each and merge
 // through LDS, which replaces a 4-fold deeper global split (partial states and merge work / 4).
-template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK>
+//
+// FUSE (pure decode steps, sequence b = token b): q/k-norm, rotary embedding and the KV-cache scatter of the
+// step's token run in front of the key stream instead of as a launch of their own.  Every work item of a
+// (sequence, kv head) normalises and rotates its G query heads from the raw projection (the arithmetic is
+// head_norm_rope, the function the separate launch uses: same bits); the item whose keys include the new
+// token's position n_k - 1 does the same for the new key, writes it and the value row to the cache slot and
+// puts both into its registers in place of what the tile load fetched from that (still unwritten) slot.
+template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK, bool FUSE = false>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const DecodeParams p) {
     // workgroup items: the waves' states (its first word later carries the arrival number of the in-launch combine)
     __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
@@ -317,6 +343,26 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 #pragma unroll
     for (int g = 0; g < G; ++g)
         qv[g] = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * G + g) * 16 + c];
+    // FUSE: does this wave's key range hold the step's new token (position n_k - 1)?  Wave-uniform.
+    const bool own_new = FUSE && n_k - 1 >= k0 && n_k - 1 < k1;
+    uint4 k_rot = make_uint4(0, 0, 0, 0), v_row = make_uint4(0, 0, 0, 0);
+    uint4 f_qwa = k_rot, f_qwb = k_rot, f_kwa = k_rot, f_kwb = k_rot;
+    int64_t f_pos = 0;
+    if (FUSE) {
+        // everything the rotation needs that does not depend on the position is requested here, in front of
+        // the first key tile; the rotation itself runs behind that tile's requests (fuse_rotate below)
+        if (own_new) {
+            k_rot = p.k_new[(int64_t)tq * p.k_stride_vec + (int64_t)h * 16 + c];
+            v_row = p.v_new[(int64_t)tq * p.v_stride_vec + (int64_t)h * 16 + c];
+        }
+        if (p.q_w != nullptr) {
+            f_qwa = p.q_w[c & 7];
+            f_qwb = p.q_w[8 + (c & 7)];
+            f_kwa = p.k_w[c & 7];
+            f_kwb = p.k_w[8 + (c & 7)];
+        }
+        f_pos = p.positions[tq];
+    }
 
     float m[G], l[G], acc[G][8];
 #pragma unroll
@@ -340,7 +386,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     int cur_blk = k0 / p.block_size;
     int cur_off = k0 - cur_blk * p.block_size;
     int cur_key = k0;
-    auto tile_load = [&](uint4 (&kd)[4], uint4 (&vd)[4]) {
+    auto tile_load = [&](uint4 (&kd)[4], uint4 (&vd)[4]) __attribute__((always_inline)) {
         if (ALIGNED) {
             int64_t phys = __builtin_amdgcn_readfirstlane(bt[cur_blk]);
             phys = phys < 0 ? 0 : (phys >= p.num_blocks ? p.num_blocks - 1 : phys);
@@ -376,7 +422,22 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     };
 
     // One tile: scores for 16 keys (4 per 16-lane row), online-softmax update, PV accumulate.
-    auto tile_compute = [&](int t, const uint4 (&kd)[4], const uint4 (&vd)[4]) {
+    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4]) __attribute__((always_inline)) {
+        if (FUSE) {
+            // the tile that holds position n_k - 1 was fetched from a slot nobody has written yet (it may hold
+            // anything, NaN bit patterns included).  The lanes behind the end of the keys re-read the tile's
+            // first row, which is that slot when n_k - 1 is the tile's first key: they take the new rows too
+            // (their probabilities are zero, but 0 x NaN is not)
+            const int jn = n_k - 1 - (k0 + 16 * t);
+            if (own_new && jn >= 0 && jn < 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool sel = ((jn >> 2) == i && (jn & 3) == kq) || (k0 + 16 * t + 4 * i + kq) >= k1;
+                    kd[i] = pick(sel, k_rot, kd[i]);
+                    vd[i] = pick(sel, v_row, vd[i]);
+                }
+            }
+        }
         float s[4][G];
         bool valid[4];
 #pragma unroll
@@ -423,13 +484,61 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 #pragma unroll
     for (int d = 0; d < kDepth; ++d)
         if (d < nt) tile_load(kbuf[d], vbuf[d]);
+    // FUSE without register prefetch: the first tile is requested here all the same, so that the rotation
+    // below runs under its round trip
+    if (FUSE && kDepth == 0 && nt > 0) tile_load(kbuf[0], vbuf[0]);
+    if (FUSE) {
+        // lane c holds piece c of a head: pieces 0..7 are x1 (first half), 8..15 are x2; head_norm_rope wants
+        // (x1 piece c', x2 piece c') in each lane of an aligned group of 8, so a lane takes its partner's piece
+        // from lane c ^ 8 (row_ror:8) and both halves of the 16-lane row compute the head; lanes c < 8 keep
+        // the rotated x1 piece, the others the x2 piece
+        const int cc = c & 7;
+        const bool upper = c >= 8;
+        const bool norm = p.q_w != nullptr;
+        const int64_t pos = f_pos < 0 ? 0 : (f_pos >= p.max_pos ? p.max_pos - 1 : f_pos);
+        const float4* cs = p.cos_sin + pos * 32;
+        const float4 c0 = cs[2 * cc], c1 = cs[2 * cc + 1];
+        const float4 s0 = cs[16 + 2 * cc], s1 = cs[16 + 2 * cc + 1];
+        auto partner = [](const uint4& x) __attribute__((always_inline)) {
+            uint4 r;
+            r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.x, 0x128, 0xF, 0xF, true);   // row_ror:8
+            r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.y, 0x128, 0xF, 0xF, true);
+            r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.z, 0x128, 0xF, 0xF, true);
+            r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.w, 0x128, 0xF, 0xF, true);
+            return r;
+        };
+        auto rotate = [&](const uint4& own, const uint4& wa, const uint4& wb) __attribute__((always_inline)) {
+            const uint4 oth = partner(own);
+            uint4 o1, o2;
+            const uint4 x1 = pick(upper, oth, own), x2 = pick(upper, own, oth);
+            if (norm) head_norm_rope<true>(x1, x2, wa, wb, c0, c1, s0, s1, p.eps, o1, o2);
+            else head_norm_rope<false>(x1, x2, wa, wb, c0, c1, s0, s1, p.eps, o1, o2);
+            return pick(upper, o2, o1);
+        };
+#pragma unroll
+        for (int g = 0; g < G; ++g) qv[g] = rotate(qv[g], f_qwa, f_qwb);
+        if (own_new) k_rot = rotate(k_rot, f_kwa, f_kwb);
+    }
+    // (no peeling: the `t == 0` below would make the compiler split off a first iteration whose fp32
+    // expressions it contracts differently from the loop's)
+#pragma nounroll
     for (int t = 0; t < nt; t += kDepth + 1) {
 #pragma unroll
         for (int u = 0; u <= kDepth; ++u) {
             if (t + u < nt) {
-                if (t + u + kDepth < nt) tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
+                if (t + u + kDepth < nt && !(FUSE && kDepth == 0 && t == 0))
+                    tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
                 tile_compute(t + u, kbuf[u], vbuf[u]);
             }
+        }
+    }
+    if (FUSE && own_new && kq == 0) {
+        // the new token's rows go to the cache behind the key stream (a store in front of it would hold back
+        // every cache load behind it: the compiler has to assume they may alias)
+        const int64_t slot = p.slots[tq];
+        if (slot >= 0 && slot < p.num_slots) {
+            p.k_cache_w[(slot * p.H_kv + h) * 16 + c] = k_rot;
+            p.v_cache_w[(slot * p.H_kv + h) * 16 + c] = v_row;
         }
     }
 
@@ -866,12 +975,26 @@ extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int 
 }
 
 namespace nv {
+// What the FUSE instantiations take beside the attention arguments (nv_attn_decode_paged_fused).
+struct FusedDecodeIn {
+    const void* k_new;
+    const void* v_new;
+    const void* q_w;
+    const void* k_w;
+    const float* cos_sin;
+    const int64_t* positions;
+    const int32_t* slots;
+    int64_t k_stride_t, v_stride_t, max_pos;
+    float eps;
+};
+
 static int decode_launch(const void* q, const void* k_cache, const void* v_cache, void* o,
                          const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                          const int32_t* block_tables, int B, int max_blocks, int max_seqlen_k, int H_q,
                          int H_kv, int D, int64_t num_blocks, int block_size, float scale,
                          int64_t q_stride_t, int64_t o_stride_t, void* workspace,
-                         int64_t workspace_bytes, bool library_workspace, void* stream) {
+                         int64_t workspace_bytes, bool library_workspace, void* stream,
+                         const FusedDecodeIn* fused = nullptr) {
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
                    num_blocks > 0 && block_size > 0,
                NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
@@ -915,6 +1038,29 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     p.q_stride_vec = q_stride_t / 8;
     p.o_stride_vec = o_stride_t / 8;
     p.scale_log2 = scale * 1.4426950408889634f;
+    p.k_new = p.v_new = p.q_w = p.k_w = nullptr;
+    p.cos_sin = nullptr;
+    p.positions = nullptr;
+    p.slots = nullptr;
+    p.k_cache_w = p.v_cache_w = nullptr;
+    p.k_stride_vec = p.v_stride_vec = p.max_pos = p.num_slots = 0;
+    p.eps = 0.f;
+    if (fused) {
+        p.k_new = (const uint4*)fused->k_new;
+        p.v_new = (const uint4*)fused->v_new;
+        p.q_w = (const uint4*)fused->q_w;
+        p.k_w = (const uint4*)fused->k_w;
+        p.cos_sin = (const float4*)fused->cos_sin;
+        p.positions = fused->positions;
+        p.slots = fused->slots;
+        p.k_cache_w = (uint4*)const_cast<void*>(k_cache);
+        p.v_cache_w = (uint4*)const_cast<void*>(v_cache);
+        p.k_stride_vec = fused->k_stride_t / 8;
+        p.v_stride_vec = fused->v_stride_t / 8;
+        p.max_pos = fused->max_pos;
+        p.num_slots = num_blocks * (int64_t)block_size;
+        p.eps = fused->eps;
+    }
     hipStream_t st = (hipStream_t)stream;
     bool single = false;
     if (p.nsplit > 1) {
@@ -934,7 +1080,8 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         // is also the default for launches with at most 8 (sequence, kv head) pairs, the one case where it
         // measured ahead of the second launch (1 sequence x 32 k keys x 8 kv heads: 31.7 - 32.0 against 32.2 - 33.0 us).
         const int sl = tuning().decode_single_launch;
-        single = (sl == 1 || (sl < 0 && library_workspace && (int64_t)B * H_kv <= 8)) && ticket_bytes <= kTicketRegion;
+        single = (sl == 1 || (sl < 0 && library_workspace && (int64_t)B * H_kv <= 8)) && ticket_bytes <= kTicketRegion &&
+                 !fused;   // (the fused instantiations carry no in-launch combine)
         if (single) {
             p.tickets = static_cast<int*>(workspace);
             if (!library_workspace) {
@@ -982,6 +1129,20 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         if (aligned) NV_DEC_LAUNCH_M2(GG, true); \
         else NV_DEC_LAUNCH_M2(GG, false);        \
     } while (0)
+#define NV_DEC_LAUNCH_F(GG)                                                                          \
+    do {                                                                                            \
+        if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);        \
+        else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 0, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
+    } while (0)
+    if (fused) {
+        NV_REQUIRE(G <= 2 && aligned, NV_ERR_UNSUPPORTED,
+                   "nv_attn_decode_paged_fused: H_q/H_kv = %d, block_size %d (supported: 1 or 2 query heads per kv "
+                   "head, block sizes that are multiples of 16); run nv_qknorm_rope_store and nv_attn_decode_paged",
+                   G, block_size);
+        if (G == 1) NV_DEC_LAUNCH_F(1);
+        else NV_DEC_LAUNCH_F(2);
+    } else
     // G = 3, 5, 6, 7 run the MFMA-score kernel laid out for the next of 4 / 8 heads
     switch (G) {
         case 1: NV_DEC_LAUNCH(1); break;
@@ -997,6 +1158,7 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
             break;
         default: NV_DEC_LAUNCH_M(8); break;
     }
+#undef NV_DEC_LAUNCH_F
 #undef NV_DEC_LAUNCH3
 #undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH
@@ -1054,6 +1216,45 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
     return nv::decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
                              max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t,
                              workspace, workspace_bytes, false, stream);
+}
+
+extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w, const void* k_w,
+                                          const float* cos_sin, const int64_t* positions,
+                                          const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
+                                          const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
+                                          int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
+                                          int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
+                                          int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                                          int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+    using namespace nv;
+    NV_REQUIRE(B >= 0 && H_kv > 0 && max_pos > 0, NV_ERR_INVALID_ARG,
+               "nv_attn_decode_paged_fused: bad sizes B=%d H_kv=%d max_pos=%lld", B, H_kv, (long long)max_pos);
+    if (B == 0) return NV_OK;
+    NV_REQUIRE(k && v && cos_sin && positions && slot_mapping, NV_ERR_INVALID_ARG,
+               "nv_attn_decode_paged_fused: null pointer");
+    NV_REQUIRE((q_w == nullptr) == (k_w == nullptr), NV_ERR_INVALID_ARG,
+               "nv_attn_decode_paged_fused: q_w and k_w must both be given or both be NULL");
+    NV_REQUIRE(k_stride_t % 8 == 0 && v_stride_t % 8 == 0 && k_stride_t >= (int64_t)H_kv * D &&
+                   v_stride_t >= (int64_t)H_kv * D,
+               NV_ERR_INVALID_ARG, "nv_attn_decode_paged_fused: bad token strides");
+    NV_REQUIRE(((uintptr_t)k | (uintptr_t)v | (uintptr_t)q_w | (uintptr_t)k_w | (uintptr_t)cos_sin) % 16 == 0,
+               NV_ERR_INVALID_ARG, "nv_attn_decode_paged_fused: pointers must be 16-byte aligned");
+    FusedDecodeIn f;
+    f.k_new = k;
+    f.v_new = v;
+    f.q_w = q_w;
+    f.k_w = k_w;
+    f.cos_sin = cos_sin;
+    f.positions = positions;
+    f.slots = slot_mapping;
+    f.k_stride_t = k_stride_t;
+    f.v_stride_t = v_stride_t;
+    f.max_pos = max_pos;
+    f.eps = eps;
+    return decode_launch(q, k_cache, v_cache, o, nullptr, cu_seqlens_k, block_tables, B, max_blocks, max_seqlen_k,
+                         H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t, workspace,
+                         workspace_bytes, false, stream, &f);
 }
 
 extern "C" int64_t nv_attn_decode_static_scratch_bytes(void) {

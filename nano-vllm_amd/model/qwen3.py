@@ -81,6 +81,7 @@ def _default_layers():
         RMSNorm = layernorm.RMSNorm
         make_rope = staticmethod(rope.make_rope)
         fused_qknorm_rope_store = staticmethod(_hip_fused)
+        fused_decode_attention = staticmethod(_hip_fused_decode)
     return _L
 
 
@@ -91,6 +92,21 @@ def _hip_fused(positions, q, k, v, q_w, k_w, rope, eps, attn):
     q_out, _ = ops.qknorm_rope_store(positions, q, k, v, q_w, k_w, rope.cos_sin_cache, eps, ctx.slot_mapping,
                                      attn.k_cache, attn.v_cache, want_k=False)
     return q_out
+
+
+def _hip_fused_decode(positions, q, k, v, q_w, k_w, rope, eps, attn):
+    """A pure decode step (every sequence has one new token, token b = sequence b): q/k-norm, rotary, KV
+    scatter and paged attention in ONE launch.  None when the step or the head shape is not one the fused
+    launch takes; the caller then runs the two launches."""
+    from .. import ops
+    ctx = get_context()
+    if ctx.max_seqlen_q > 1 or q.shape[0] != ctx.cu_seqlens_k.numel() - 1:
+        return None
+    if not ops.decode_fused_supported(q.shape[1], k.shape[1], attn.k_cache.shape[1]):
+        return None
+    return ops.attn_decode_paged_fused(positions, q, k, v, q_w, k_w, rope.cos_sin_cache, eps, ctx.slot_mapping,
+                                       attn.k_cache, attn.v_cache, ctx.cu_seqlens_k, ctx.block_tables,
+                                       ctx.max_seqlen_k, attn.attn_scale)
 
 
 class Qwen3Attention(nn.Module):
@@ -120,6 +136,7 @@ class Qwen3Attention(nn.Module):
         self.attention = L.Attention(self.num_heads, self.head_dim, self.num_kv_heads, self.head_dim ** -0.5,
                                      cfg.max_position_embeddings)
         self._fused = L.fused_qknorm_rope_store if fused else None
+        self._fused_decode = getattr(L, "fused_decode_attention", None) if fused else None
 
     def fuse_weights(self) -> None:
         """Make q/k/v_proj.weight views of ONE [q+2kv, hidden] tensor so the three projections run
@@ -148,9 +165,14 @@ class Qwen3Attention(nn.Module):
     def forward(self, x: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         q, k, v = self._project(x)
         if self._fused is not None:
-            q = self._fused(positions, q, k, v, self.q_norm.weight if self.qk_norm else None,
-                            self.k_norm.weight if self.qk_norm else None, self.rope, self.eps, self.attention)
-            o = self.attention.attend(q)
+            q_w = self.q_norm.weight if self.qk_norm else None
+            k_w = self.k_norm.weight if self.qk_norm else None
+            o = None
+            if self._fused_decode is not None:
+                o = self._fused_decode(positions, q, k, v, q_w, k_w, self.rope, self.eps, self.attention)
+            if o is None:
+                q = self._fused(positions, q, k, v, q_w, k_w, self.rope, self.eps, self.attention)
+                o = self.attention.attend(q)
         else:
             if self.qk_norm:
                 q, k = self.q_norm(q), self.k_norm(k)

@@ -155,6 +155,56 @@ def attn_prefill_varlen(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
     return out
 
 
+def decode_fused_supported(hq: int, hkv: int, block_size: int) -> bool:
+    """Shapes nv_attn_decode_paged_fused takes (others run qknorm_rope_store + attn_decode_paged)."""
+    return hq % hkv == 0 and hq // hkv <= 2 and block_size % 16 == 0
+
+
+def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            q_weight: Optional[torch.Tensor], k_weight: Optional[torch.Tensor],
+                            cos_sin: torch.Tensor, eps: float, slot_mapping: torch.Tensor,
+                            k_cache: torch.Tensor, v_cache: torch.Tensor, cu_seqlens_k: torch.Tensor,
+                            block_tables: torch.Tensor, max_seqlen_k: int, scale: float,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A pure decode step's q/k-norm + rotary + KV scatter + paged attention in one launch (token b is
+    sequence b's only new token).  Bit-identical to qknorm_rope_store followed by attn_decode_paged."""
+    _rope_common(positions, q, k, cos_sin)
+    B = _attn_common(q, k_cache, v_cache, cu_seqlens_k, block_tables)
+    nb, bs, hkv, d = k_cache.shape
+    hq = q.shape[1]
+    _need(q.shape[0] == B, "one query token per sequence")
+    _need(k.shape[1:] == (hkv, d), "k rows do not match the cache rows")
+    _gpu_bf16(v, "v")
+    _rows_ok(v, "v")
+    _need(v.shape == k.shape, "k/v shape mismatch")
+    _i32(slot_mapping, "slot_mapping")
+    _need(slot_mapping.numel() == B, "slot_mapping length != number of sequences")
+    _need((q_weight is None) == (k_weight is None), "q_weight and k_weight go together")
+    if q_weight is not None:
+        _gpu_bf16(q_weight, "q_weight")
+        _gpu_bf16(k_weight, "k_weight")
+        _need(q_weight.numel() == d and k_weight.numel() == d, "norm weights must be [head_dim]")
+    if out is None:
+        out = torch.empty((B, hq, d), dtype=_BF16, device=q.device)
+    else:
+        _gpu_bf16(out, "out")
+        _rows_ok(out, "out")
+        _need(out.shape == q.shape, "out shape != q shape")
+    dll = _lib.lib()
+    need = dll.nv_attn_decode_workspace_bytes(B, hq, hkv, d, int(max_seqlen_k))
+    ws = _workspace(q.device, need)
+    rc = dll.nv_attn_decode_paged_fused(
+        q.data_ptr(), k.data_ptr(), v.data_ptr(),
+        q_weight.data_ptr() if q_weight is not None else None,
+        k_weight.data_ptr() if k_weight is not None else None,
+        cos_sin.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+        out.data_ptr(), cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B, block_tables.shape[1],
+        int(max_seqlen_k), hq, hkv, d, nb, bs, cos_sin.shape[0], float(eps), float(scale),
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), ws.data_ptr(), ws.numel(), _stream(q))
+    _lib.check(rc, "nv_attn_decode_paged_fused")
+    return out
+
+
 def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     """y = bf16(silu(f32(gate)) * f32(up)) for x = [gate | up] along the last dimension."""
     _need(x.is_cuda, "x must be a GPU tensor (this path has no CPU implementation)")

@@ -18,10 +18,10 @@ int main(int argc, char** argv) {
     BIND(nv_strerror) BIND(nv_last_error) BIND(nv_abi_version) BIND(nv_store_kvcache)
     BIND(nv_set_tuning) BIND(nv_get_tuning)
     BIND(nv_attn_decode_workspace_bytes) BIND(nv_attn_decode_paged)
-    BIND(nv_attn_decode_static_scratch_bytes) BIND(nv_attn_decode_paged_static)
+    BIND(nv_attn_decode_static_scratch_bytes) BIND(nv_attn_decode_paged_static) BIND(nv_attn_decode_paged_fused)
     BIND(nv_attn_prefill_workspace_bytes) BIND(nv_attn_prefill_varlen)
     BIND(nv_rmsnorm) BIND(nv_add_rmsnorm) BIND(nv_silu_and_mul) BIND(nv_rope) BIND(nv_qknorm_rope_store)
-    if (p_nv_abi_version() < 4) { printf("abi %d\n", p_nv_abi_version()); return 3; }
+    if (p_nv_abi_version() < 5) { printf("abi %d\n", p_nv_abi_version()); return 3; }
     if (strcmp(p_nv_strerror(NV_OK), "ok") != 0) return 4;
     /* unsupported head_dim: refused before any device access */
     int rc = p_nv_attn_prefill_varlen(0, 0, 0, 0, 0, 0, 0, 1, 1, 8, 8, 16, 8, 64, 1, 256, 1.0f, 2048, 2048, 0, 8, 0, 0, 0);

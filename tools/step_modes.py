@@ -30,13 +30,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--two-launch", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     side = torch.cuda.Stream(dev)
     with torch.cuda.stream(side):
         w = bench.Workload(dev, 28, 256, 513, 768, seed=0)
-        plan = w.build_plan(False)          # launches go to `side` (the current stream at plan time)
+        plan = w.build_plan(False, not a.two_launch)   # launches go to `side` (the current stream at plan time)
         for _ in range(3):
             bench.run_step(plan)
         side.synchronize()
@@ -50,7 +51,7 @@ def main():
             rows["sampled"].append(timed(lambda: bench.run_step(plan, ev, phase=len(ev)), a.steps, dev))
             rows["plain"].append(timed(lambda: bench.run_step(plan), a.steps, dev))
             rows["graph"].append(timed(g.replay, a.steps, dev))
-    nbytes = w.step_bytes(False)
+    nbytes = w.step_bytes(False, not a.two_launch)
     for k, v in rows.items():
         v.sort()
         med = v[len(v) // 2]
