@@ -111,7 +111,7 @@ class Workload:
         self.cos_sin = build_cos_sin_cache(self.D, self.MAX_POS, self.ROPE_BASE).to(dev).view(self.MAX_POS, self.D)
         self.scale = self.D ** -0.5
         # preallocated outputs (the timed region allocates nothing)
-        self.q_rot = torch.empty(batch, self.H_Q, self.D, dtype=torch.bfloat16, device=dev)
+        self.q_rot = torch.randn(batch, self.H_Q, self.D, generator=gen, device=dev).bfloat16()
         self.o = torch.empty(batch, self.H_Q, self.D, dtype=torch.bfloat16, device=dev)
         self.y = torch.empty_like(self.hidden)
         self.new_res = torch.empty_like(self.hidden)
@@ -686,6 +686,22 @@ def main():
     value = step_bytes_all / (elapsed / args.steps) / 1e9
     attn_ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
     achieved = w.attn_bytes_per_launch() / (attn_ms * 1e-3) / 1e9
+    # beside the one-launch step: the attention launch on its own (rotated queries in, nothing stored), three
+    # untimed-for-`value` passes over the layers with an event pair around every launch
+    attn_alone = None
+    if one_launch and rank == 0:
+        plan_a = w.build_plan(True, False)
+        ev_a = []
+        run_step(plan_a)
+        for _ in range(3):
+            run_step(plan_a, ev_a, every=1)
+        torch.cuda.synchronize(dev)
+        ms_a = sum(a.elapsed_time(b) for a, b in ev_a) / len(ev_a)
+        gbps_a = w.attn_bytes_per_launch() / (ms_a * 1e-3) / 1e9
+        attn_alone = {"kernel": "attn_decode_kernel (nv_attn_decode_paged: the attention launch without the fused "
+                                "q/k-norm, rotary and scatter)", "launch_ms": round(ms_a, 5),
+                      "achieved": round(gbps_a, 1), "unit": "GB/s", "frac": round(gbps_a / HBM_PEAK_GBPS, 4)}
+        del plan_a
 
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu_kv = (w.kv_cache[0, 0].cpu(), w.kv_cache[1, 0].cpu()) if want_cpu else None
@@ -761,6 +777,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source, "launch_ms": round(attn_ms, 5),
                          "algorithmic_bytes_per_launch": w.attn_bytes_per_launch()},
         }
+        if attn_alone is not None:
+            out["attention_launch_alone"] = attn_alone
         if extra_prefill is not None:
             out["prefill"] = extra_prefill
             if ceiling is not None:

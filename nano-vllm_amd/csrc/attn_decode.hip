@@ -328,6 +328,8 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     if (b >= p.B) return;
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
+    // FUSE: the token's position is read with the sequence's bounds (one scalar round trip for all three)
+    const int64_t f_pos_raw = FUSE ? p.positions[b] : 0;
     int tq = b;
     if (p.cu_q) {
         if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // not a decode row
@@ -347,10 +349,10 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     const bool own_new = FUSE && n_k - 1 >= k0 && n_k - 1 < k1;
     uint4 k_rot = make_uint4(0, 0, 0, 0), v_row = make_uint4(0, 0, 0, 0);
     uint4 f_qwa = k_rot, f_qwb = k_rot, f_kwa = k_rot, f_kwb = k_rot;
-    int64_t f_pos = 0;
+    float4 f_c0 = make_float4(0.f, 0.f, 0.f, 0.f), f_c1 = f_c0, f_s0 = f_c0, f_s1 = f_c0;
     if (FUSE) {
-        // everything the rotation needs that does not depend on the position is requested here, in front of
-        // the first key tile; the rotation itself runs behind that tile's requests (fuse_rotate below)
+        // everything the rotation needs is requested here, in front of the first key tile; the rotation
+        // itself runs behind that tile's requests
         if (own_new) {
             k_rot = p.k_new[(int64_t)tq * p.k_stride_vec + (int64_t)h * 16 + c];
             v_row = p.v_new[(int64_t)tq * p.v_stride_vec + (int64_t)h * 16 + c];
@@ -361,7 +363,16 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
             f_kwa = p.k_w[c & 7];
             f_kwb = p.k_w[8 + (c & 7)];
         }
-        f_pos = p.positions[tq];
+        // the position is a scalar read like the sequence's bounds above, so the cos / sin row can be
+        // requested here as well: every request of the rotation then sits in front of the first key tile's,
+        // and the rotation waits for them only (the memory counter retires in order)
+        int64_t pos = f_pos_raw;           // (token b is sequence b's: this form takes no cu_seqlens_q)
+        pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+        const float4* cs = p.cos_sin + pos * 32;
+        f_c0 = cs[2 * (c & 7)];
+        f_c1 = cs[2 * (c & 7) + 1];
+        f_s0 = cs[16 + 2 * (c & 7)];
+        f_s1 = cs[16 + 2 * (c & 7) + 1];
     }
 
     float m[G], l[G], acc[G][8];
@@ -492,13 +503,9 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
         // (x1 piece c', x2 piece c') in each lane of an aligned group of 8, so a lane takes its partner's piece
         // from lane c ^ 8 (row_ror:8) and both halves of the 16-lane row compute the head; lanes c < 8 keep
         // the rotated x1 piece, the others the x2 piece
-        const int cc = c & 7;
         const bool upper = c >= 8;
         const bool norm = p.q_w != nullptr;
-        const int64_t pos = f_pos < 0 ? 0 : (f_pos >= p.max_pos ? p.max_pos - 1 : f_pos);
-        const float4* cs = p.cos_sin + pos * 32;
-        const float4 c0 = cs[2 * cc], c1 = cs[2 * cc + 1];
-        const float4 s0 = cs[16 + 2 * cc], s1 = cs[16 + 2 * cc + 1];
+        const float4 c0 = f_c0, c1 = f_c1, s0 = f_s0, s1 = f_s1;
         auto partner = [](const uint4& x) __attribute__((always_inline)) {
             uint4 r;
             r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.x, 0x128, 0xF, 0xF, true);   // row_ror:8
@@ -515,9 +522,31 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
             else head_norm_rope<false>(x1, x2, wa, wb, c0, c1, s0, s1, p.eps, o1, o2);
             return pick(upper, o2, o1);
         };
+        // Every 16-lane row of the wave holds the same G query heads (and the new key): row r rotates item r
+        // of (query heads 0 .. G-1, key) and the results are passed round, one pass of the arithmetic instead
+        // of G + 1 (the rotation's VALU time is in front of the wave's first tile: 2.1 us of the launch with
+        // three passes at G = 2)
+        static_assert(!FUSE || G + 1 <= 4, "one item per 16-lane row");
+        uint4 item = k_rot, wa = f_kwa, wb = f_kwb;
 #pragma unroll
-        for (int g = 0; g < G; ++g) qv[g] = rotate(qv[g], f_qwa, f_qwb);
-        if (own_new) k_rot = rotate(k_rot, f_kwa, f_kwb);
+        for (int g = 0; g < G; ++g) {
+            item = pick(kq == g, qv[g], item);
+            wa = pick(kq == g, f_qwa, wa);
+            wb = pick(kq == g, f_qwb, wb);
+        }
+        const uint4 done = rotate(item, wa, wb);
+        auto from_row = [&](int r) __attribute__((always_inline)) {
+            const int src = (16 * r + c) * 4;
+            uint4 o;
+            o.x = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)done.x);
+            o.y = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)done.y);
+            o.z = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)done.z);
+            o.w = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)done.w);
+            return o;
+        };
+#pragma unroll
+        for (int g = 0; g < G; ++g) qv[g] = from_row(g);
+        if (own_new) k_rot = from_row(G);
     }
     // (no peeling: the `t == 0` below would make the compiler split off a first iteration whose fp32
     // expressions it contracts differently from the loop's)
