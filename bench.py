@@ -741,14 +741,15 @@ def main():
                 src = os.path.join(ROOT, "nano-vllm_amd", "csrc", "attn_decode.hip")
                 sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
                 default_wl = (args.batch, args.ctx_lo, args.ctx_hi) == (256, 513, 768)
-                if rec.get("kernel_source_sha256") == sha and default_wl:
+                # (the passes are taken on the one-launch step's kernel)
+                if rec.get("kernel_source_sha256") == sha and default_wl and one_launch:
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_source = {"file": "profiles/decode_traffic.json", "commit": rec.get("commit"),
                                       "kernel_source_sha256": sha[:16], "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                       "separate passes, FETCH_SIZE doubled (gfx950)"}
                 else:
                     traffic_source = {"file": "profiles/decode_traffic.json", "stale": True,
-                                      "reason": "kernel source or workload differs from the PMC passes"}
+                                      "reason": "kernel source, launch form or workload differs from the PMC passes"}
             except Exception:
                 traffic = None
         out = {
