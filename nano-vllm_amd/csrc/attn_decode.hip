@@ -495,9 +495,13 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
 #pragma unroll
     for (int d = 0; d < kDepth; ++d)
         if (d < nt) tile_load(kbuf[d], vbuf[d]);
-    // FUSE without register prefetch: the first tile is requested here all the same, so that the rotation
-    // below runs under its round trip
-    if (FUSE && kDepth == 0 && nt > 0) tile_load(kbuf[0], vbuf[0]);
+    // FUSE without register prefetch: the first TWO tiles are requested here all the same (the second into
+    // registers of its own that are dead afterwards), so that the rotation below runs under their round trip
+    // and the wave has made up for it by the time it enters the loop
+    uint4 kx[4], vx[4];
+    const bool ahead1 = FUSE && kDepth == 0 && nt > 0, ahead2 = ahead1 && nt > 1;
+    if (ahead1) tile_load(kbuf[0], vbuf[0]);
+    if (ahead2) tile_load(kx, vx);
     if (FUSE) {
         // lane c holds piece c of a head: pieces 0..7 are x1 (first half), 8..15 are x2; head_norm_rope wants
         // (x1 piece c', x2 piece c') in each lane of an aligned group of 8, so a lane takes its partner's piece
@@ -548,14 +552,20 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
         for (int g = 0; g < G; ++g) qv[g] = from_row(g);
         if (own_new) k_rot = from_row(G);
     }
-    // (no peeling: the `t == 0` below would make the compiler split off a first iteration whose fp32
-    // expressions it contracts differently from the loop's)
-#pragma nounroll
-    for (int t = 0; t < nt; t += kDepth + 1) {
+    int t_first = 0;
+    if (ahead1) {
+        tile_compute(0, kbuf[0], vbuf[0]);
+        t_first = 1;
+    }
+    if (ahead2) {
+        tile_compute(1, kx, vx);
+        t_first = 2;
+    }
+    for (int t = t_first; t < nt; t += kDepth + 1) {
 #pragma unroll
         for (int u = 0; u <= kDepth; ++u) {
             if (t + u < nt) {
-                if (t + u + kDepth < nt && !(FUSE && kDepth == 0 && t == 0))
+                if (t + u + kDepth < nt)
                     tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
                 tile_compute(t + u, kbuf[u], vbuf[u]);
             }
