@@ -346,7 +346,11 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     for (int g = 0; g < G; ++g)
         qv[g] = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * G + g) * 16 + c];
     // FUSE: does this wave's key range hold the step's new token (position n_k - 1)?  Wave-uniform.
-    const bool own_new = FUSE && n_k - 1 >= k0 && n_k - 1 < k1;
+    // (A caller whose max_seqlen_k is smaller than this sequence's key count gets the keys behind the planned
+    // range ignored by the attention, as in the separate launch; the cache must stay right all the same, so the
+    // last work item of the range takes the token then.)
+    const bool last_item = split == p.nsplit - 1 && (!WGS || wave == kDecWaves - 1);
+    const bool own_new = FUSE && n_k - 1 >= k0 && (n_k - 1 < k1 || last_item);
     uint4 k_rot = make_uint4(0, 0, 0, 0), v_row = make_uint4(0, 0, 0, 0);
     uint4 f_qwa = k_rot, f_qwb = k_rot, f_kwa = k_rot, f_kwb = k_rot;
     float4 f_c0 = make_float4(0.f, 0.f, 0.f, 0.f), f_c1 = f_c0, f_s0 = f_c0, f_s1 = f_c0;

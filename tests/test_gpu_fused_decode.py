@@ -161,6 +161,17 @@ def test_fused_step_padded_rows_and_bad_slots(hip):
     assert torch.equal(bits(a[1]), bits(b[1])) and torch.equal(bits(a[2]), bits(b[2]))
 
 
+def test_fused_step_stores_the_token_even_when_max_seqlen_k_is_understated(hip):
+    """A max_seqlen_k below a sequence's key count is a caller's error that costs that sequence its last keys in
+    either form; the scatter must not depend on it (a token missing from the cache would spoil every later step)."""
+    ctx = [700, 130, 1500]
+    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(13, ctx, 16, 8, 256, True)
+    p = dict(p, max_k=1024)
+    a, b = _both(hip, p, q, k, v, q_w, k_w, cos_sin, pos, slots)
+    assert torch.equal(bits(a[1]), bits(b[1])) and torch.equal(bits(a[2]), bits(b[2]))
+    _assert_out(a[0][:2], b[0][:2], "rows inside the bound")
+
+
 def test_fused_step_refuses_wide_head_groups(hip):
     from nanovllm_amd import _lib
     st = _step(1, [100, 200], 32, 8, 256, True)
