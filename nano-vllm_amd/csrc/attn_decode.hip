@@ -634,9 +634,16 @@ constexpr float kDecRaise = 8.0f;
 // G is the head count the kernel is laid out for (4 or 8); the launch may have fewer query heads per
 // kv head (p.G = 3, 5, 6, 7: e.g. 40 query / 8 kv heads): the surplus columns are zero queries whose
 // results are not stored.
-template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK>
+//
+// FUSE: as in attn_decode_kernel (raw projections in, the step's token normalised, rotated and stored by the
+// launch).  The rotation runs in that kernel's layout -- lane (row, c) holds piece c of item 4 j + row of (query
+// heads 0 .. p.G - 1, new key) in pass j -- and the rotated heads cross a per-wave LDS area into the operand
+// layouts of this kernel: Q fragments for every lane, the new key's fragments for the lanes of its tile row.
+template <int G, bool ALIGNED, int kDepth, bool WGS, bool TK, bool FUSE = false>
 __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const DecodeParams p) {
     static_assert(G == 4 || G == 8, "query heads per kv head");
+    constexpr int kFusePasses = (G + 1 + 3) / 4;      // items (query heads + key) over the wave's four rows
+    __shared__ uint4 fstage_all[FUSE ? kDecWaves : 1][FUSE ? (G + 1) * 16 : 1];
     __shared__ __attribute__((aligned(16))) float xch_all[kDecWaves][16 * G + 16];
     // workgroup items: the waves' states (its first word later carries the arrival number of the in-launch combine)
     __shared__ __attribute__((aligned(16))) float wg_sm[WGS ? kDecWaves * G * kPartStride : 4];
@@ -668,12 +675,47 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
 
     // B operand: lane (c, r4) holds Q[head c][dims 32 s + 8 r4 .. +7] for k-step s
     bf16x8 qf[4];
+    if (!FUSE) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < p.G) v = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * p.G + c) * 16 + 4 * s + r4];
-        qf[s] = __builtin_bit_cast(bf16x8, v);
+        for (int s = 0; s < 4; ++s) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < p.G) v = p.q[(int64_t)tq * p.q_stride_vec + (int64_t)(h * p.G + c) * 16 + 4 * s + r4];
+            qf[s] = __builtin_bit_cast(bf16x8, v);
+        }
     }
+    // FUSE: the raw rows of the wave's items, the value row, the norm weights and the cos / sin row are all
+    // requested here, in front of the first key tile (see attn_decode_kernel)
+    const bool last_item = split == p.nsplit - 1 && (!WGS || wave == kDecWaves - 1);
+    const bool own_new = FUSE && n_k - 1 >= k0 && (n_k - 1 < k1 || last_item);
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 f_raw[kFusePasses], v_row = zero4, f_qwa = zero4, f_qwb = zero4, f_kwa = zero4, f_kwb = zero4;
+    float4 f_c0 = make_float4(0.f, 0.f, 0.f, 0.f), f_c1 = f_c0, f_s0 = f_c0, f_s1 = f_c0;
+    if (FUSE) {
+#pragma unroll
+        for (int j = 0; j < kFusePasses; ++j) {
+            const int it = 4 * j + r4;
+            const uint4* src = it < p.G ? p.q + (int64_t)tq * p.q_stride_vec + (int64_t)(h * p.G + it) * 16 + c
+                                        : p.k_new + (int64_t)tq * p.k_stride_vec + (int64_t)h * 16 + c;
+            uint4 x = zero4;
+            if (it < p.G || (it == p.G && own_new)) x = *src;
+            f_raw[j] = x;
+        }
+        if (own_new) v_row = p.v_new[(int64_t)tq * p.v_stride_vec + (int64_t)h * 16 + c];
+        if (p.q_w != nullptr) {
+            f_qwa = p.q_w[c & 7];
+            f_qwb = p.q_w[8 + (c & 7)];
+            f_kwa = p.k_w[c & 7];
+            f_kwb = p.k_w[8 + (c & 7)];
+        }
+        int64_t pos = p.positions[b];      // (token b is sequence b's: this form takes no cu_seqlens_q)
+        pos = pos < 0 ? 0 : (pos >= p.max_pos ? p.max_pos - 1 : pos);
+        const float4* cs = p.cos_sin + pos * 32;
+        f_c0 = cs[2 * (c & 7)];
+        f_c1 = cs[2 * (c & 7) + 1];
+        f_s0 = cs[16 + 2 * (c & 7)];
+        f_s1 = cs[16 + 2 * (c & 7) + 1];
+    }
+    uint4 k_frag_new[4] = {zero4, zero4, zero4, zero4}, k_store = zero4;   // FUSE: the new key in both layouts
 
     float m_run = kNegBig, l_part = 0.f;
     float acc[G][8];
@@ -749,7 +791,23 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         }
     };
 
-    auto tile_compute = [&](int t, const uint4 (&kd)[4], const uint4 (&vd)[4]) {
+    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4]) __attribute__((always_inline)) {
+        if (FUSE) {
+            // the tile that holds position n_k - 1 was fetched from a slot nobody has written yet: the lanes of
+            // its key row take the new key's fragments, the lanes of its value row -- and those behind the end
+            // of the keys, which re-read the tile's first row -- the new value row (0 x NaN is not 0; a stale K
+            // row only reaches scores that are masked by a select)
+            const int jn = n_k - 1 - (k0 + 16 * t);
+            if (own_new && jn >= 0 && jn < 16) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) kd[s] = pick(c == jn, k_frag_new[s], kd[s]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool sel = (4 * i + r4) == jn || (k0 + 16 * t + 4 * i + r4) >= k1;
+                    vd[i] = pick(sel, v_row, vd[i]);
+                }
+            }
+        }
         f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 4; ++s)
@@ -816,6 +874,39 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
 #pragma unroll
     for (int d = 0; d < kDepth; ++d)
         if (d < nt) tile_load(kbuf[d], vbuf[d]);
+    if (FUSE) {
+        uint4* stage = fstage_all[wave];
+        const bool upper = c >= 8;
+        const bool norm = p.q_w != nullptr;
+#pragma unroll
+        for (int j = 0; j < kFusePasses; ++j) {
+            const int it = 4 * j + r4;
+            const bool is_q = it < p.G;
+            const uint4 own = f_raw[j];
+            uint4 oth;
+            oth.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.x, 0x128, 0xF, 0xF, true);   // row_ror:8
+            oth.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.y, 0x128, 0xF, 0xF, true);
+            oth.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.z, 0x128, 0xF, 0xF, true);
+            oth.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)own.w, 0x128, 0xF, 0xF, true);
+            const uint4 x1 = pick(upper, oth, own), x2 = pick(upper, own, oth);
+            const uint4 wa = pick(is_q, f_qwa, f_kwa), wb = pick(is_q, f_qwb, f_kwb);
+            uint4 o1, o2;
+            if (norm) head_norm_rope<true>(x1, x2, wa, wb, f_c0, f_c1, f_s0, f_s1, p.eps, o1, o2);
+            else head_norm_rope<false>(x1, x2, wa, wb, f_c0, f_c1, f_s0, f_s1, p.eps, o1, o2);
+            if (it <= p.G) stage[it * 16 + c] = pick(upper, o2, o1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 v = zero4;
+            if (c < p.G) v = stage[c * 16 + 4 * s + r4];
+            qf[s] = __builtin_bit_cast(bf16x8, v);
+            k_frag_new[s] = stage[p.G * 16 + 4 * s + r4];
+        }
+        k_store = stage[p.G * 16 + c];
+    }
     for (int t = 0; t < nt; t += kDepth + 1) {
 #pragma unroll
         for (int u = 0; u <= kDepth; ++u) {
@@ -823,6 +914,14 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
                 if (t + u + kDepth < nt) tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
                 tile_compute(t + u, kbuf[u], vbuf[u]);
             }
+        }
+    }
+    if (FUSE && own_new && r4 == 0) {
+        // the new token's rows go to the cache behind the key stream (see attn_decode_kernel)
+        const int64_t slot = p.slots[b];
+        if (slot >= 0 && slot < p.num_slots) {
+            p.k_cache_w[(slot * p.H_kv + h) * 16 + c] = k_store;
+            p.v_cache_w[(slot * p.H_kv + h) * 16 + c] = v_row;
         }
     }
 
@@ -1178,13 +1277,21 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 0, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
         else hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
     } while (0)
+#define NV_DEC_LAUNCH_MF(GG)                                                                         \
+    do {                                                                                            \
+        if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \
+        else if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 0, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);               \
+    } while (0)
     if (fused) {
-        NV_REQUIRE(G <= 2 && aligned, NV_ERR_UNSUPPORTED,
-                   "nv_attn_decode_paged_fused: H_q/H_kv = %d, block_size %d (supported: 1 or 2 query heads per kv "
-                   "head, block sizes that are multiples of 16); run nv_qknorm_rope_store and nv_attn_decode_paged",
-                   G, block_size);
+        NV_REQUIRE(aligned && (G <= 2 || use_mfma), NV_ERR_UNSUPPORTED,
+                   "nv_attn_decode_paged_fused: block_size %d, H_q/H_kv = %d (supported: block sizes that are multiples "
+                   "of 16; more than two query heads per kv head on the MFMA score path only); run "
+                   "nv_qknorm_rope_store and nv_attn_decode_paged", block_size, G);
         if (G == 1) NV_DEC_LAUNCH_F(1);
-        else NV_DEC_LAUNCH_F(2);
+        else if (G == 2) NV_DEC_LAUNCH_F(2);
+        else if (G <= 4) NV_DEC_LAUNCH_MF(4);
+        else NV_DEC_LAUNCH_MF(8);
     } else
     // G = 3, 5, 6, 7 run the MFMA-score kernel laid out for the next of 4 / 8 heads
     switch (G) {
@@ -1202,6 +1309,7 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         default: NV_DEC_LAUNCH_M(8); break;
     }
 #undef NV_DEC_LAUNCH_F
+#undef NV_DEC_LAUNCH_MF
 #undef NV_DEC_LAUNCH3
 #undef NV_DEC_LAUNCH2
 #undef NV_DEC_LAUNCH

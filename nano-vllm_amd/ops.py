@@ -157,7 +157,7 @@ def attn_prefill_varlen(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.T
 
 def decode_fused_supported(hq: int, hkv: int, block_size: int) -> bool:
     """Shapes nv_attn_decode_paged_fused takes (others run qknorm_rope_store + attn_decode_paged)."""
-    return hq % hkv == 0 and hq // hkv <= 2 and block_size % 16 == 0
+    return hq % hkv == 0 and hq // hkv <= 8 and block_size % 16 == 0
 
 
 def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,

@@ -89,7 +89,8 @@ def hip():
 
 
 @pytest.mark.parametrize("norm", [True, False])
-@pytest.mark.parametrize("H_q,H_kv", [(16, 8), (8, 8), (2, 1), (4, 4)])
+@pytest.mark.parametrize("H_q,H_kv", [(16, 8), (8, 8), (2, 1), (4, 4), (32, 8), (64, 8), (8, 1), (24, 8), (40, 8),
+                                      (7, 1)])
 def test_fused_step_equals_two_launches(hip, H_q, H_kv, norm):
     # ragged contexts: first key, tile and block boundaries on either side, several blocks
     ctx = [1, 2, 15, 16, 17, 255, 256, 257, 300, 511, 512, 513, 700, 768, 1025]
@@ -98,16 +99,18 @@ def test_fused_step_equals_two_launches(hip, H_q, H_kv, norm):
     _assert_same(a, b, f"H{H_q}/{H_kv} norm={norm}")
 
 
+@pytest.mark.parametrize("H_q", [16, 32])
 @pytest.mark.parametrize("bs", [16, 64, 512])
-def test_fused_step_block_sizes(hip, bs):
+def test_fused_step_block_sizes(hip, bs, H_q):
     ctx = [1, bs - 1, bs, bs + 1, 3 * bs, 3 * bs + 5, 777]
-    st = _step(5, ctx, 16, 8, bs, True, strided=False)
+    st = _step(5, ctx, H_q, 8, bs, True, strided=False)
     a, b = _both(hip, *st)
-    _assert_same(a, b, f"block {bs}")
+    _assert_same(a, b, f"H{H_q}/8 block {bs}")
 
 
+@pytest.mark.parametrize("H_q", [16, 32, 64])
 @pytest.mark.parametrize("B,ctx_hi,wi", [(1, 9000, -1), (2, 32768, -1), (3, 5000, 0), (3, 5000, 1), (8, 2100, -1)])
-def test_fused_step_with_split_sequences(hip, B, ctx_hi, wi):
+def test_fused_step_with_split_sequences(hip, B, ctx_hi, wi, H_q):
     """Few sequences with long contexts: the keys are cut into work items (waves or workgroups, both
     forced), only the item that holds position n_k - 1 takes the new token, and the merge launch follows."""
     from nanovllm_amd import _lib
@@ -118,10 +121,10 @@ def test_fused_step_with_split_sequences(hip, B, ctx_hi, wi):
         ctx[1] = ctx_hi // 2 + 1        # a sequence whose last work items are empty
     _lib.set_tuning(decode_work_item=wi)
     try:
-        assert _lib.lib().nv_attn_decode_workspace_bytes(B, 16, 8, D, max(ctx)) > 16, "this case must split"
-        st = _step(11, ctx, 16, 8, 256, True)
+        assert _lib.lib().nv_attn_decode_workspace_bytes(B, H_q, 8, D, max(ctx)) > 16, "this case must split"
+        st = _step(11, ctx, H_q, 8, 256, True)
         a, b = _both(hip, *st)
-        _assert_same(a, b, f"B{B} ctx<={ctx_hi} work item {wi}")
+        _assert_same(a, b, f"H{H_q}/8 B{B} ctx<={ctx_hi} work item {wi}")
     finally:
         _lib.set_tuning()
 
@@ -135,11 +138,12 @@ def test_fused_step_headline_batch(hip):
     _assert_same(a, b, "headline")
 
 
-def test_fused_step_padded_rows_and_bad_slots(hip):
+@pytest.mark.parametrize("H_q", [16, 32])
+def test_fused_step_padded_rows_and_bad_slots(hip, H_q):
     """Rows a captured graph pads its batch with (no keys, slot -1) and a slot outside the cache: nothing is
     written for them, the attention of the out-of-range row still sees its new token."""
     ctx = [300, 40, 513]
-    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(9, ctx, 16, 8, 256, True)
+    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(9, ctx, H_q, 8, 256, True)
     # append two padded rows
     pad = 2
     cu_k = torch.cat([p["cu_k"], p["cu_k"][-1:].repeat(pad)])
@@ -161,20 +165,28 @@ def test_fused_step_padded_rows_and_bad_slots(hip):
     assert torch.equal(bits(a[1]), bits(b[1])) and torch.equal(bits(a[2]), bits(b[2]))
 
 
-def test_fused_step_stores_the_token_even_when_max_seqlen_k_is_understated(hip):
+@pytest.mark.parametrize("H_q", [16, 64])
+def test_fused_step_stores_the_token_even_when_max_seqlen_k_is_understated(hip, H_q):
     """A max_seqlen_k below a sequence's key count is a caller's error that costs that sequence its last keys in
     either form; the scatter must not depend on it (a token missing from the cache would spoil every later step)."""
     ctx = [700, 130, 1500]
-    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(13, ctx, 16, 8, 256, True)
+    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(13, ctx, H_q, 8, 256, True)
     p = dict(p, max_k=1024)
     a, b = _both(hip, p, q, k, v, q_w, k_w, cos_sin, pos, slots)
     assert torch.equal(bits(a[1]), bits(b[1])) and torch.equal(bits(a[2]), bits(b[2]))
     _assert_out(a[0][:2], b[0][:2], "rows inside the bound")
 
 
-def test_fused_step_refuses_wide_head_groups(hip):
+def test_fused_step_refuses_what_it_has_no_kernel_for(hip):
+    """More than two query heads per kv head run the MFMA-score kernel; with that path switched off by the
+    tuning record there is no fused kernel for them, and more than eight heads per kv head have none at all."""
     from nanovllm_amd import _lib
     st = _step(1, [100, 200], 32, 8, 256, True)
-    with pytest.raises(_lib.NanoVllmHipError, match="query heads per kv"):
-        _both(hip, *st)
-    assert not hip.decode_fused_supported(32, 8, 256) and hip.decode_fused_supported(16, 8, 256)
+    _lib.set_tuning(decode_score_path=0)
+    try:
+        with pytest.raises(_lib.NanoVllmHipError, match="MFMA score path"):
+            _both(hip, *st)
+    finally:
+        _lib.set_tuning()
+    assert hip.decode_fused_supported(32, 8, 256) and hip.decode_fused_supported(16, 8, 256)
+    assert not hip.decode_fused_supported(16, 1, 256) and not hip.decode_fused_supported(16, 8, 8)
