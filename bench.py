@@ -390,6 +390,43 @@ def decode_config_records(dev, iters=40):
         out.append({"workload": f"{cfg_name}: batch {B}, ctx {ctx}, H {H_q}/{H_kv} per GPU, block {bs}",
                     "bytes": nbytes, "ms": round(ms, 5), "achieved_GBps": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                     "frac": round(gbps / HBM_PEAK_GBPS, 4)})
+
+        # the decode step's whole attention block at this shape: the scatter launch (q/k-norm + rotary + KV store)
+        # followed by the attention launch, against the one launch that does both (raw projections in)
+        q_raw = torch.randn(B, H_q, D, device=dev).bfloat16()
+        k_raw = torch.randn(B, H_kv, D, device=dev).bfloat16()
+        v_raw = torch.randn(B, H_kv, D, device=dev).bfloat16()
+        q_w = (1 + 0.1 * torch.randn(D, device=dev)).bfloat16()
+        k_w = (1 + 0.1 * torch.randn(D, device=dev)).bfloat16()
+        max_pos = ctx
+        cos_sin = torch.randn(max_pos, D, device=dev, dtype=torch.float32)
+        positions = torch.full((B,), ctx - 1, dtype=torch.int64, device=dev)
+        slots = (bt[:, (ctx - 1) // bs].long() * bs + (ctx - 1) % bs).to(torch.int32)
+
+        def two_launches(l):
+            rc = dll.nv_qknorm_rope_store(q_raw.data_ptr(), k_raw.data_ptr(), v_raw.data_ptr(), q_w.data_ptr(),
+                                          k_w.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(), slots.data_ptr(),
+                                          caches[l][0].data_ptr(), caches[l][1].data_ptr(), q.data_ptr(), None, B, H_q,
+                                          H_kv, D, max_pos, 1e-6, NB, bs, q_raw.stride(0), k_raw.stride(0),
+                                          v_raw.stride(0), stream)
+            if rc != 0:
+                _lib.check(rc, "nv_qknorm_rope_store")
+            launch(l)
+
+        def one_launch(l):
+            rc = dll.nv_attn_decode_paged_fused(q_raw.data_ptr(), k_raw.data_ptr(), v_raw.data_ptr(), q_w.data_ptr(),
+                                                k_w.data_ptr(), cos_sin.data_ptr(), positions.data_ptr(),
+                                                slots.data_ptr(), caches[l][0].data_ptr(), caches[l][1].data_ptr(),
+                                                o.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B, width, ctx, H_q, H_kv,
+                                                D, NB, bs, max_pos, 1e-6, D ** -0.5, q_raw.stride(0), k_raw.stride(0),
+                                                v_raw.stride(0), o.stride(0), ws.data_ptr(), ws.numel(), stream)
+            if rc != 0:
+                _lib.check(rc, "nv_attn_decode_paged_fused")
+        try:
+            out[-1]["ms_scatter_then_attention"] = round(_time_launches(two_launches, L, iters, dev), 5)
+            out[-1]["ms_one_launch"] = round(_time_launches(one_launch, L, iters, dev), 5)
+        except Exception as e:              # the attention record above stands on its own
+            out[-1]["one_launch_error"] = f"{type(e).__name__}: {e}"
         del caches
         torch.cuda.empty_cache()
     return out

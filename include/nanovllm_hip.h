@@ -232,8 +232,8 @@ NV_API int nv_qknorm_rope_store(const void* q, const void* k, const void* v, con
  *   sees the new token.
  *   k_cache, v_cache: read for keys 0 .. n_k - 2 and WRITTEN at the new token's slot.
  *   The remaining arguments, the workspace and the results are nv_attn_decode_paged's.
- * Shapes: H_q / H_kv of 1 or 2 and block sizes that are multiples of 16; NV_ERR_UNSUPPORTED otherwise
- * (run the two launches then).
+ * Shapes: H_q / H_kv of 1 .. 8 (3 .. 8 on the MFMA score path, which is the default for them) and block sizes that
+ * are multiples of 16; NV_ERR_UNSUPPORTED otherwise (run the two launches then).
  */
 NV_API int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w,
                                const void* k_w, const float* cos_sin, const int64_t* positions,

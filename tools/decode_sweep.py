@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ctx-hi", type=int, default=768)
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
     ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -69,7 +70,7 @@ def main():
                 a.record()
                 for l in range(w.L):
                     args_ = (w.q_rot.data_ptr(), w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(),
-                             w.o.data_ptr(), w.cu_q.data_ptr(), w.cu_k.data_ptr(), w.block_tables.data_ptr(), w.B,
+                             w.o.data_ptr(), None if args.no_cu_q else w.cu_q.data_ptr(), w.cu_k.data_ptr(), w.block_tables.data_ptr(), w.B,
                              w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB, w.BS, w.scale,
                              w.q_rot.stride(0), w.o.stride(0))
                     if mode == "static":       # the allocation-free entry point (in-launch combine by default)
