@@ -20,6 +20,7 @@
 // including the one stored earlier in the same forward, :230-231).
 #include "nv_common.h"
 #include "norm_rope_shared.h"
+#include <type_traits>
 
 // Build-time tuning knobs (defaults are the measured best on MI355X).
 #ifndef NV_DEC_WAVES
@@ -437,8 +438,8 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     };
 
     // One tile: scores for 16 keys (4 per 16-lane row), online-softmax update, PV accumulate.
-    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4]) __attribute__((always_inline)) {
-        if (FUSE) {
+    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4], auto may_patch) __attribute__((always_inline)) {
+        if constexpr (FUSE && decltype(may_patch)::value) {
             // the tile that holds position n_k - 1 was fetched from a slot nobody has written yet (it may hold
             // anything, NaN bit patterns included).  The lanes behind the end of the keys re-read the tile's
             // first row, which is that slot when n_k - 1 is the tile's first key: they take the new rows too
@@ -557,21 +558,46 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
         if (own_new) k_rot = from_row(G);
     }
     int t_first = 0;
+    constexpr std::true_type kPatch{};
+    constexpr std::false_type kNoPatch{};
     if (ahead1) {
-        tile_compute(0, kbuf[0], vbuf[0]);
+        tile_compute(0, kbuf[0], vbuf[0], kPatch);
         t_first = 1;
     }
     if (ahead2) {
-        tile_compute(1, kx, vx);
+        tile_compute(1, kx, vx, kPatch);
         t_first = 2;
     }
-    for (int t = t_first; t < nt; t += kDepth + 1) {
+    if constexpr (FUSE) {
+        // position n_k - 1 can only lie in the wave's LAST tile: the groups of tiles in front of it run the
+        // plain kernel's loop (no patch code, none of its registers live across the loop); measured 107.3 ->
+        // 106.5 us on the 256-sequence ragged batch next to 106.0 for the attention launch alone
+        int t = t_first;
+        for (; t + kDepth + 1 <= nt - 1; t += kDepth + 1) {
+#pragma unroll
+            for (int u = 0; u <= kDepth; ++u) {
+                if (t + u + kDepth < nt)
+                    tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
+                tile_compute(t + u, kbuf[u], vbuf[u], kNoPatch);
+            }
+        }
 #pragma unroll
         for (int u = 0; u <= kDepth; ++u) {
             if (t + u < nt) {
                 if (t + u + kDepth < nt)
                     tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
-                tile_compute(t + u, kbuf[u], vbuf[u]);
+                tile_compute(t + u, kbuf[u], vbuf[u], kPatch);
+            }
+        }
+    } else {
+        for (int t = t_first; t < nt; t += kDepth + 1) {
+#pragma unroll
+            for (int u = 0; u <= kDepth; ++u) {
+                if (t + u < nt) {
+                    if (t + u + kDepth < nt)
+                        tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
+                    tile_compute(t + u, kbuf[u], vbuf[u], kPatch);
+                }
             }
         }
     }
@@ -791,8 +817,8 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         }
     };
 
-    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4]) __attribute__((always_inline)) {
-        if (FUSE) {
+    auto tile_compute = [&](int t, uint4 (&kd)[4], uint4 (&vd)[4], auto may_patch) __attribute__((always_inline)) {
+        if constexpr (FUSE && decltype(may_patch)::value) {
             // the tile that holds position n_k - 1 was fetched from a slot nobody has written yet: the lanes of
             // its key row take the new key's fragments, the lanes of its value row -- and those behind the end
             // of the keys, which re-read the tile's first row -- the new value row (0 x NaN is not 0; a stale K
@@ -907,12 +933,14 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         }
         k_store = stage[p.G * 16 + c];
     }
+    // (peeling the patched last tile off the loop, as attn_decode_kernel does, measured 1 - 4 % slower here)
+    constexpr std::true_type kPatch{};
     for (int t = 0; t < nt; t += kDepth + 1) {
 #pragma unroll
         for (int u = 0; u <= kDepth; ++u) {
             if (t + u < nt) {
                 if (t + u + kDepth < nt) tile_load(kbuf[(u + kDepth) % (kDepth + 1)], vbuf[(u + kDepth) % (kDepth + 1)]);
-                tile_compute(t + u, kbuf[u], vbuf[u]);
+                tile_compute(t + u, kbuf[u], vbuf[u], kPatch);
             }
         }
     }

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
-    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point)")
+    ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point),fused (one-launch step)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
@@ -75,6 +75,14 @@ def main():
                              w.q_rot.stride(0), w.o.stride(0))
                     if mode == "static":       # the allocation-free entry point (in-launch combine by default)
                         rc = dll.nv_attn_decode_paged_static(*args_, stream)
+                    elif mode == "fused":      # the one-launch step: raw projections in, token stored by the launch
+                        rc = dll.nv_attn_decode_paged_fused(
+                            w.q_in.data_ptr(), w.k_in.data_ptr(), w.v_in.data_ptr(), w.q_w.data_ptr(), w.k_w.data_ptr(),
+                            w.cos_sin.data_ptr(), w.positions.data_ptr(), w.slots.data_ptr(),
+                            w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(), w.o.data_ptr(), w.cu_k.data_ptr(),
+                            w.block_tables.data_ptr(), w.B, w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB,
+                            w.BS, w.MAX_POS, w.EPS, w.scale, w.q_in.stride(0), w.k_in.stride(0), w.v_in.stride(0),
+                            w.o.stride(0), ws.data_ptr(), ws.numel(), stream)
                     else:
                         rc = dll.nv_attn_decode_paged(*args_, ws.data_ptr(), ws.numel(), stream)
                     assert rc == 0, dll.nv_last_error()
