@@ -135,3 +135,32 @@ def test_head_shard_ranges():
     one = HeadShard(0, 1, 16, 8)
     x = torch.zeros(2, 16, 128)
     assert all_gather_heads(x, one) is x
+
+
+def _bench_reduce_worker(rank, world, port, result_path):
+    """bench.py's cross-rank arithmetic on gloo: the step time is the MAX over the ranks, the bytes their SUM,
+    and the per-rank device records come back in rank order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        t = bench.reduce_scalar(dist, torch.device("cpu"), 1.0 + rank, "max")
+        b = bench.reduce_scalar(dist, torch.device("cpu"), 100.0 * (rank + 1), "sum")
+        ids = bench._gather_objects(dist, world, {"rank": rank})
+        ok = t == float(world) and b == 100.0 * world * (world + 1) / 2 and [d["rank"] for d in ids] == list(range(world))
+        alone = bench.reduce_scalar(None, torch.device("cpu"), 3.5, "max") == 3.5 and \
+            bench._gather_objects(None, 1, "x") == ["x"]
+        flags = [torch.zeros(1) for _ in range(world)]
+        dist.all_gather(flags, torch.tensor([1.0 if ok and alone else 0.0]))
+        if rank == 0:
+            with open(result_path, "w") as f:
+                f.write("ok" if all(x.item() == 1.0 for x in flags) else "mismatch")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_aggregates_over_ranks_world2(tmp_path):
+    result = tmp_path / "result.txt"
+    mp.spawn(_bench_reduce_worker, args=(2, _free_port(), str(result)), nprocs=2, join=True)
+    assert result.read_text() == "ok"
