@@ -71,11 +71,16 @@ class Workload:
     H_Q, H_KV, D, HIDDEN, BS = 16, 8, 128, 1024, 256
     EPS, MAX_POS, ROPE_BASE = 1e-6, 40960, 1e6
 
-    def __init__(self, dev, layers, batch, lo, hi, seed=0):
+    def __init__(self, dev, layers, batch, lo, hi, seed=0, long_tail=()):
+        """`long_tail`: (count, length) pairs that replace the first sequences' lengths (tuning aid: skewed batches)."""
         from nanovllm_amd.layers.rope import build_cos_sin_cache
         self.dev, self.L, self.B = dev, layers, batch
         g = torch.Generator().manual_seed(seed)
         self.ctx = torch.randint(lo, hi + 1, (batch,), generator=g).tolist()
+        i = 0
+        for count, length in long_tail:
+            self.ctx[i:i + count] = [length] * count
+            i += count
         blocks = [math.ceil(c / self.BS) for c in self.ctx]
         self.NB = sum(blocks)
         perm = torch.randperm(self.NB, generator=g).tolist()

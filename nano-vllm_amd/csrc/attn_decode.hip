@@ -108,10 +108,12 @@ struct DecodeParams {
 
 // Final state of one (sequence, query head, key chunk) held by 16 lanes (lane c: dims 8c..8c+7):
 // written as the bf16 output when the sequence is not split, else as an fp32 partial state.
+// `direct`: the sequence has a single key range in this launch (always when the launch is unsplit; in a split
+// launch, every sequence no longer than one chunk): its output row is final, no partial state, no merge work.
 template <bool TK>
 __device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq, int split, int tq, int c,
-                                            float m, float l, const float (&a)[8]) {
-    if (p.nsplit == 1) {
+                                            float m, float l, const float (&a)[8], bool direct) {
+    if (direct) {
         const float inv = l > 0.f ? 1.0f / l : 0.f;
         uint4 ov;
         ov.x = pack_bf16(a[0] * inv, a[1] * inv);
@@ -147,7 +149,7 @@ __device__ __forceinline__ void store_state(const DecodeParams& p, int b, int hq
 template <int G, bool TK>
 __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm, int wave, int lane, int b, int h,
                                                int split, int tq, const float (&m)[G], const float (&l)[G],
-                                               const float (&acc)[G][8]) {
+                                               const float (&acc)[G][8], bool direct) {
     const int c = lane & 15;
     if (lane < 16) {
 #pragma unroll
@@ -180,7 +182,7 @@ __device__ __forceinline__ void wg_merge_store(const DecodeParams& p, float* sm,
             a[4] += y.x * f; a[5] += y.y * f; a[6] += y.z * f; a[7] += y.w * f;
             ls += src[kHeadDim + 1] * f;
         }
-        store_state<TK>(p, b, h * p.G + g, split, tq, c, mm, ls, a);
+        store_state<TK>(p, b, h * p.G + g, split, tq, c, mm, ls, a, direct);
     }
 }
 
@@ -269,7 +271,7 @@ __device__ __forceinline__ void wave_merge_heads(const DecodeParams& p, int b, i
 __device__ __forceinline__ void wave_ticket_merge(const DecodeParams& p, int b, int h, int tq, int n_k, int lane) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int ns = (n_k + p.chunk - 1) / p.chunk;
-    ns = ns < 1 ? 1 : ns;
+    ns = ns < 1 ? 1 : (ns > p.nsplit ? p.nsplit : ns);
     int* ticket = p.tickets + (int64_t)b * p.H_kv + h;
     int old = 0;
     if (lane == 0) old = ticket_arrive(ticket);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void wg_ticket_merge(const DecodeParams& p, int* flag
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int ns = (n_k + p.chunk - 1) / p.chunk;
-    ns = ns < 1 ? 1 : ns;
+    ns = ns < 1 ? 1 : (ns > p.nsplit ? p.nsplit : ns);
     int* ticket = p.tickets + (int64_t)b * p.H_kv + h;
     if (threadIdx.x == 0) *flag = ticket_arrive(ticket);
     __syncthreads();
@@ -298,6 +300,10 @@ __device__ __forceinline__ void wg_ticket_merge(const DecodeParams& p, int* flag
     __syncthreads();
     wave_merge_heads(p, b, h, tq, ns, lane, wave, kDecWaves);
 }
+
+#ifndef NV_DEC_SPLIT_MAJOR
+#define NV_DEC_SPLIT_MAJOR 1
+#endif
 
 // kDepth = tiles (8 KiB per wave each) kept in flight ahead of the one being consumed.
 // WGS = false: every wave is its own work item.  WGS = true (launches with few (sequence, head)
@@ -324,9 +330,18 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
+#if NV_DEC_SPLIT_MAJOR
+    // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
+    // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
+    // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
+    const int b = rest % p.B;
+    const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
+    if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
+#else
     const int split = rest % p.nsplit;
     const int b = rest / p.nsplit;
     if (b >= p.B) return;
+#endif
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     // FUSE: the token's position is read with the sequence's bounds (one scalar round trip for all three)
@@ -341,6 +356,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     // this wave's keys [k0, k1): the whole chunk, or its wave-th quarter (a multiple of 16 keys)
     const int k0 = WGS ? kc0 + wave * (p.chunk / kDecWaves) : kc0;
     const int k1 = WGS ? min(min(kc0 + p.chunk, n_k), k0 + p.chunk / kDecWaves) : min(kc0 + p.chunk, n_k);
+    const bool direct = p.nsplit == 1 || n_k <= p.chunk;   // a single key range: the output row is written at once
 
     uint4 qv[G];
 #pragma unroll
@@ -632,15 +648,15 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     }
 
     if (WGS) {
-        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
-        if (TK) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
+        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc, direct);
+        if (TK && !direct) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
         return;
     }
     if (kq == 0) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) store_state<TK>(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g]);
+        for (int g = 0; g < G; ++g) store_state<TK>(p, b, h * G + g, split, tq, c, m[g], l[g], acc[g], direct);
     }
-    if (TK) wave_ticket_merge(p, b, h, tq, n_k, lane);
+    if (TK && !direct) wave_ticket_merge(p, b, h, tq, n_k, lane);
 }
 
 // Variant for G >= 4 query heads per kv head.  The per-(key, head) lane reductions of the
@@ -683,9 +699,18 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
+#if NV_DEC_SPLIT_MAJOR
+    // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
+    // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
+    // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
+    const int b = rest % p.B;
+    const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
+    if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
+#else
     const int split = rest % p.nsplit;
     const int b = rest / p.nsplit;
     if (b >= p.B) return;
+#endif
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     int tq = b;
@@ -698,6 +723,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     // this wave's keys [k0, k1): the whole chunk, or its wave-th quarter (a multiple of 16 keys)
     const int k0 = WGS ? kc0 + wave * (p.chunk / kDecWaves) : kc0;
     const int k1 = WGS ? min(min(kc0 + p.chunk, n_k), k0 + p.chunk / kDecWaves) : min(kc0 + p.chunk, n_k);
+    const bool direct = p.nsplit == 1 || n_k <= p.chunk;   // a single key range: the output row is written at once
 
     // B operand: lane (c, r4) holds Q[head c][dims 32 s + 8 r4 .. +7] for k-step s
     bf16x8 qf[4];
@@ -979,16 +1005,16 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
         }
 
     if (WGS) {
-        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc);
-        if (TK) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
+        wg_merge_store<G, TK>(p, wg_sm, wave, lane, b, h, split, tq, m, l, acc, direct);
+        if (TK && !direct) wg_ticket_merge(p, reinterpret_cast<int*>(wg_sm), b, h, tq, n_k, wave, lane);
         return;
     }
     if (r4 == 0) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
-            if (g < p.G) store_state<TK>(p, b, h * p.G + g, split, tq, c, m[g], l[g], acc[g]);
+            if (g < p.G) store_state<TK>(p, b, h * p.G + g, split, tq, c, m[g], l[g], acc[g], direct);
     }
-    if (TK) wave_ticket_merge(p, b, h, tq, n_k, lane);
+    if (TK && !direct) wave_ticket_merge(p, b, h, tq, n_k, lane);
 }
 
 // Combine the per-chunk partial states of one (sequence, query head): 32 threads x 4 dims.
@@ -1012,8 +1038,9 @@ __global__ __launch_bounds__(256) void attn_decode_merge_kernel(const DecodePara
         if (p.cu_q[b + 1] - p.cu_q[b] != 1) return;  // uniform per block in both forms
         tq = p.cu_q[b];
     }
+    if (n_k <= p.chunk) return;   // a single key range: written by the attention launch itself (uniform per block)
     int ns = (n_k + p.chunk - 1) / p.chunk;
-    ns = ns < 1 ? 1 : ns;  // split 0 always writes a (possibly empty) state
+    ns = ns > p.nsplit ? p.nsplit : ns;   // (a caller's max_seqlen_k below this sequence's key count)
     const float* base = p.part + ((int64_t)b * H_q + hq) * p.nsplit * kPartStride;
     const int s0 = SG == 1 ? 0 : grp;
     float mmax = kNegBig;
@@ -1119,7 +1146,10 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
         if (want < 1) want = 1;
         long long chunk = (max_k + want - 1) / want;
         chunk = (chunk + 63) / 64 * 64;
-        const long long lo = d.wgs ? 64 * kDecWaves : 64, hi = d.wgs ? 4096 * kDecWaves : 4096;
+        // (2048 keys per wave at most: in a batch of short sequences with a few long ones the long ones' waves are
+        // the launch's tail -- one 8192-key sequence among 256 of ~640 keys: 279 us at 4096 keys per wave, 237 at
+        // 2048 -- while sequences of up to one chunk are written directly and never see the merge)
+        const long long lo = d.wgs ? 64 * kDecWaves : 64, hi = d.wgs ? 2048 * kDecWaves : 2048;
         chunk = chunk < lo ? lo : (chunk > hi ? hi : chunk);
         d.chunk = (int)chunk;
     }
