@@ -437,6 +437,43 @@ def decode_config_records(dev, iters=40):
     return out
 
 
+def decode_skew_records(dev, iters=20):
+    """The decode launch on skewed batches of the headline shape (256 sequences of 513 .. 767 keys plus a few long
+    ones): planned from max_seqlen_k alone (what the reference's call passes) against planned with the chunk
+    nv_attn_decode_suggest_chunk derives from the sum of the lengths (what a runner that holds them can pass)."""
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = []
+    for label, long_tail in (("one of 8192 keys", [(1, 8192)]), ("four of 4096 keys", [(4, 4096)]),
+                             ("one of 32768 keys", [(1, 32768)])):
+        w = Workload(dev, 4, 256 + sum(c for c, _ in long_tail), 513, 767, long_tail=long_tail)
+        chunk = dll.nv_attn_decode_suggest_chunk(w.B, w.H_Q, w.H_KV, w.max_k, sum(w.ctx))
+        ws = torch.empty(max(16, dll.nv_attn_decode_workspace_bytes_chunked(w.B, w.H_Q, w.H_KV, w.D, w.max_k, chunk),
+                             dll.nv_attn_decode_workspace_bytes(w.B, w.H_Q, w.H_KV, w.D, w.max_k)),
+                         dtype=torch.uint8, device=dev)
+
+        def launch(l, ck):
+            rc = dll.nv_attn_decode_paged_chunked(w.q_rot.data_ptr(), w.kv_cache[0, l].data_ptr(),
+                                                  w.kv_cache[1, l].data_ptr(), w.o.data_ptr(), w.cu_q.data_ptr(),
+                                                  w.cu_k.data_ptr(), w.block_tables.data_ptr(), w.B,
+                                                  w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB, w.BS,
+                                                  w.scale, w.q_rot.stride(0), w.o.stride(0), ws.data_ptr(), ws.numel(),
+                                                  ck, stream)
+            if rc != 0:
+                _lib.check(rc, "nv_attn_decode_paged_chunked")
+        ms_plain = _time_launches(lambda l: launch(l, 0), w.L, iters, dev)
+        ms_hint = _time_launches(lambda l: launch(l, chunk), w.L, iters, dev)
+        nbytes = w.attn_bytes_per_launch()
+        out.append({"workload": f"256 sequences of 513..767 keys and {label}, H {w.H_Q}/{w.H_KV}, block {w.BS}",
+                    "bytes": nbytes, "ms_planned_from_max": round(ms_plain, 5), "suggested_chunk": chunk,
+                    "ms_with_suggested_chunk": round(ms_hint, 5),
+                    "GBps_with_suggested_chunk": round(nbytes / (ms_hint * 1e-3) / 1e9, 1)})
+        del w, ws
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline_other(seconds_each: float = 3.0):
     """The oracle's remaining kernels on the host cores, bounded samples: KV scatter, residual-add RMSNorm,
     rotary embedding (GB/s of the same algorithmic bytes as the GPU kernels) and prefill attention (TFLOP/s)."""
@@ -762,13 +799,14 @@ def main():
     tp = None if args.no_tp else guarded(tp_bench, args, dev, rank, world, dist)
     dp5 = None if args.no_tp else guarded(dp_config5_bench, args, dev, rank, world, dist)
 
-    extra_prefill = extra_cfg = ceiling = None
+    extra_prefill = extra_cfg = extra_skew = ceiling = None
     if rank == 0 and not args.no_prefill:
         ceiling = guarded(mfma_ceiling_record, dev)
         ceil_tf = ceiling.get("achieved_tflops") if isinstance(ceiling, dict) else None
         extra_prefill = guarded(prefill_records, dev, ceiling_tflops=ceil_tf)
     if rank == 0 and not args.no_configs:
         extra_cfg = guarded(decode_config_records, dev)
+        extra_skew = guarded(decode_skew_records, dev)
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be
@@ -828,6 +866,8 @@ def main():
                 out["mfma_ceiling"] = ceiling
         if extra_cfg is not None:
             out["decode_by_config"] = extra_cfg
+        if extra_skew is not None:
+            out["decode_skewed_batches"] = extra_skew
         if tp is not None:
             out["head_sharded"] = tp
         if dp5 is not None:

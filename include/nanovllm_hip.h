@@ -105,6 +105,32 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
                          void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * The decode launch for hosts that know more of the batch than its longest sequence.  No counterpart in the
+ * reference, whose flash_attn_varlen_func call (nanovllm/layers/attention.py:241-252) passes max_seqlen_k only --
+ * but its runner holds every length as a host integer (nanovllm/engine/model_runner.py:85-89).
+ * The launch plan cuts long sequences into key ranges of `chunk` keys, one work item each.  From max_seqlen_k
+ * alone it cannot tell 256 sequences of 2048 keys (no cut wanted) from 255 of 640 keys and one of 8192 (whose
+ * few waves end the launch long after the others unless its keys are spread over many work items).
+ *   nv_attn_decode_suggest_chunk: keys per work item for a batch with this sum of lengths, or 0 when the
+ *     plan's own choice stands (balanced batches, launches with few (sequence, kv head) pairs).
+ *   nv_attn_decode_paged_chunked / nv_attn_decode_paged_fused_chunked: the entry points above with that value
+ *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 64 ranges per sequence).
+ *     Results equal the unhinted launch's up to the fp32 summation order of the merge.
+ *   nv_attn_decode_workspace_bytes_chunked: the workspace such a launch needs.
+ * Sequences of at most chunk keys are written by the attention launch directly, whatever the others need.
+ */
+NV_API int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_seqlen_k, int64_t sum_seqlen_k);
+NV_API int64_t nv_attn_decode_workspace_bytes_chunked(int B, int H_q, int H_kv, int D, int max_seqlen_k,
+                                                      int chunk_keys);
+NV_API int nv_attn_decode_paged_chunked(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                        const int32_t* block_tables, int B, int max_blocks,
+                                        int max_seqlen_k, int H_q, int H_kv, int D,
+                                        int64_t num_blocks, int block_size, float scale,
+                                        int64_t q_stride_t, int64_t o_stride_t,
+                                        void* workspace, int64_t workspace_bytes, int chunk_keys, void* stream);
+
+/*
  * nv_attn_decode_paged without a workspace argument, for callers that cannot allocate device memory
  * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no
  * counterpart in the reference.  Same arguments, kernels and results as nv_attn_decode_paged; the
@@ -243,6 +269,16 @@ NV_API int nv_attn_decode_paged_fused(const void* q, const void* k, const void* 
                                int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
                                int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
                                int64_t o_stride_t, void* workspace, int64_t workspace_bytes, void* stream);
+/* ... with the host's choice of keys per work item (see nv_attn_decode_suggest_chunk above) */
+NV_API int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, const void* v, const void* q_w,
+                               const void* k_w, const float* cos_sin, const int64_t* positions,
+                               const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
+                               const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
+                               int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
+                               int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
+                               int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                               int64_t o_stride_t, void* workspace, int64_t workspace_bytes, int chunk_keys,
+                               void* stream);
 
 #ifdef __cplusplus
 }

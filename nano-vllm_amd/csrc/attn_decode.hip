@@ -301,10 +301,6 @@ __device__ __forceinline__ void wg_ticket_merge(const DecodeParams& p, int* flag
     wave_merge_heads(p, b, h, tq, ns, lane, wave, kDecWaves);
 }
 
-#ifndef NV_DEC_SPLIT_MAJOR
-#define NV_DEC_SPLIT_MAJOR 1
-#endif
-
 // kDepth = tiles (8 KiB per wave each) kept in flight ahead of the one being consumed.
 // WGS = false: every wave is its own work item.  WGS = true (launches with few (sequence, head)
 // pairs): the workgroup is one work item, its waves take a quarter of the chunk each and merge
@@ -330,18 +326,12 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
-#if NV_DEC_SPLIT_MAJOR
     // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
     // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
     // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
     const int b = rest % p.B;
     const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
     if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
-#else
-    const int split = rest % p.nsplit;
-    const int b = rest / p.nsplit;
-    if (b >= p.B) return;
-#endif
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     // FUSE: the token's position is read with the sequence's bounds (one scalar round trip for all three)
@@ -699,18 +689,12 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
     const int h = item % p.H_kv;
     const int rest = item / p.H_kv;
-#if NV_DEC_SPLIT_MAJOR
     // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
     // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
     // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
     const int b = rest % p.B;
     const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
     if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
-#else
-    const int split = rest % p.nsplit;
-    const int b = rest / p.nsplit;
-    if (b >= p.B) return;
-#endif
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     int tq = b;
@@ -1118,7 +1102,9 @@ static bool decode_uses_mfma(int G, const nv_tuning& tn) {
     return G >= 4;
 }
 
-static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
+// chunk_keys > 0: the caller's choice of keys per work item (nv_attn_decode_paged_chunked: a host that knows the
+// batch's lengths, not only the longest); the process-wide override still wins.
+static DecodePlan plan_decode(int B, int H_kv, int max_k, int G, int chunk_keys = 0) {
     const nv_tuning tn = tuning();
     DecodePlan d;
     d.mfma = decode_uses_mfma(G, tn);
@@ -1137,6 +1123,12 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
                                      : (bh * 2 <= target && (H_kv <= 2 || wave_keys < 1024));
     if (tn.decode_chunk > 0) {
         d.chunk = tn.decode_chunk;
+    } else if (chunk_keys > 0) {
+        // a multiple of 64 keys (of 256 for workgroup items), and at most 64 ranges per sequence
+        const long long unit = d.wgs ? 64 * kDecWaves : 64;
+        long long chunk = ((long long)chunk_keys + unit - 1) / unit * unit;
+        const long long least = (((long long)max_k + 63) / 64 + unit - 1) / unit * unit;
+        d.chunk = (int)(chunk < least ? least : chunk);
     } else {
         // Fewest splits that still give the launch about `target` waves; unsplit sequences are
         // written directly (no partials, no merge launch).  Chunks are capped so that one long
@@ -1158,6 +1150,7 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
     // Prefetch depth: one tile ahead hides HBM latency when each wave streams a long chunk
     // and waves are scarce; with many resident waves (or G = 8, where registers are the
     // limit) thread-level parallelism already covers it and the leaner kernel is faster.
+    // (the lean kernel for split launches of many pairs as well measured 4 - 15 % slower on skewed batches)
     d.lean = G >= 8 || (d.nsplit == 1 && bh >= NV_DEC_TARGET_WAVES);
     // one tile of prefetch measured faster than none on every G >= 4 shape tried
     d.mfma_deep = tn.decode_mfma_depth >= 0 ? tn.decode_mfma_depth == 1 : true;
@@ -1166,12 +1159,45 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G) {
 
 }  // namespace nv
 
-extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k) {
+extern "C" int64_t nv_attn_decode_workspace_bytes_chunked(int B, int H_q, int H_kv, int D, int max_seqlen_k,
+                                                          int chunk_keys) {
     using namespace nv;
     if (B <= 0 || H_q <= 0 || H_kv <= 0 || D != kHeadDim || max_seqlen_k < 0) return 0;
-    const int ns = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv).nsplit;
+    const int ns = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv, chunk_keys).nsplit;
     if (ns == 1) return 16;
     return kTicketRegion + (int64_t)B * H_q * ns * kPartStride * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t nv_attn_decode_workspace_bytes(int B, int H_q, int H_kv, int D, int max_seqlen_k) {
+    return nv_attn_decode_workspace_bytes_chunked(B, H_q, H_kv, D, max_seqlen_k, 0);
+}
+
+// Keys per work item for a batch whose lengths the host knows (their sum beside their maximum); 0 = the plan's
+// own choice stands.  The plan sees only the longest sequence: it cannot tell 256 sequences of 2048 keys (no
+// split wanted: 4 - 9 % slower with one) from 255 of 640 and one of 8192 (whose waves are the launch's tail
+// unless its keys are spread over many work items).  Measured on gfx950 (256 sequences of 513 .. 767 keys plus
+// the long ones, 8 kv heads): one 8192-key sequence 225 us with the plan's 2048-key chunks, 153 with 512;
+// four of 4096 keys 217 -> 145; one of 32768 keys 276 -> 249 (1024-key chunks: more ranges cost more empty
+// work items than they save).
+extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_seqlen_k, int64_t sum_seqlen_k) {
+    using namespace nv;
+    if (B <= 0 || H_q <= 0 || H_kv <= 0 || H_q % H_kv != 0 || max_seqlen_k <= 0 || sum_seqlen_k <= 0) return 0;
+    const DecodePlan d = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv);
+    const long long bh = (long long)B * H_kv;
+    const long long target = d.mfma ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES;
+    if (bh < target) return 0;                 // few pairs: the plan splits for occupancy already
+    const long long mean = (sum_seqlen_k + B - 1) / B;
+    // balanced enough: the longest sequence within 1.4 x the mean, or less than 512 keys beyond it (a split
+    // costs a merge launch and partial states: about 6 us)
+    if ((long long)max_seqlen_k * 5 < mean * 7 || max_seqlen_k - mean < 512) return 0;
+    // pieces of about three quarters of a mean sequence; twice that for the MFMA-score kernels, whose partial
+    // states hold 4 - 8 query heads per kv head (64 / 8 heads, one 8192-key sequence among 256 of ~640 keys:
+    // 172 us with 512-key pieces, 155 with 1024, 192 planned from the longest length alone)
+    long long chunk = ((d.mfma ? mean * 3 / 2 : mean * 3 / 4) + 63) / 64 * 64;
+    if (chunk < 256) chunk = 256;
+    const long long most = 32;                                  // ranges per sequence (empty work items are not free)
+    if (((long long)max_seqlen_k + chunk - 1) / chunk > most) chunk = ((max_seqlen_k + most - 1) / most + 63) / 64 * 64;
+    return chunk < d.chunk ? (int)chunk : 0;
 }
 
 namespace nv {
@@ -1194,7 +1220,7 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
                          int H_kv, int D, int64_t num_blocks, int block_size, float scale,
                          int64_t q_stride_t, int64_t o_stride_t, void* workspace,
                          int64_t workspace_bytes, bool library_workspace, void* stream,
-                         const FusedDecodeIn* fused = nullptr) {
+                         const FusedDecodeIn* fused = nullptr, int chunk_keys = 0) {
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
                    num_blocks > 0 && block_size > 0,
                NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
@@ -1230,7 +1256,8 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     p.max_blocks = max_blocks;
     p.H_kv = H_kv;
     p.block_size = block_size;
-    const DecodePlan plan = plan_decode(B, H_kv, max_seqlen_k, G);
+    NV_REQUIRE(chunk_keys >= 0, NV_ERR_INVALID_ARG, "nv_attn_decode_paged: chunk_keys %d < 0", chunk_keys);
+    const DecodePlan plan = plan_decode(B, H_kv, max_seqlen_k, G, chunk_keys);
     p.chunk = plan.chunk;
     p.nsplit = plan.nsplit;
     p.G = G;
@@ -1427,15 +1454,27 @@ extern "C" int nv_attn_decode_paged(const void* q, const void* k_cache, const vo
                              workspace, workspace_bytes, false, stream);
 }
 
-extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w, const void* k_w,
-                                          const float* cos_sin, const int64_t* positions,
-                                          const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
-                                          const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
-                                          int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
-                                          int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
-                                          int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
-                                          int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
-                                          void* stream) {
+extern "C" int nv_attn_decode_paged_chunked(const void* q, const void* k_cache, const void* v_cache, void* o,
+                                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                                            const int32_t* block_tables, int B, int max_blocks,
+                                            int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
+                                            int block_size, float scale, int64_t q_stride_t,
+                                            int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
+                                            int chunk_keys, void* stream) {
+    return nv::decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
+                             max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t,
+                             workspace, workspace_bytes, false, stream, nullptr, chunk_keys);
+}
+
+extern "C" int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, const void* v, const void* q_w,
+                                                  const void* k_w, const float* cos_sin, const int64_t* positions,
+                                                  const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
+                                                  const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
+                                                  int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
+                                                  int64_t num_blocks, int block_size, int64_t max_pos, float eps,
+                                                  float scale, int64_t q_stride_t, int64_t k_stride_t,
+                                                  int64_t v_stride_t, int64_t o_stride_t, void* workspace,
+                                                  int64_t workspace_bytes, int chunk_keys, void* stream) {
     using namespace nv;
     NV_REQUIRE(B >= 0 && H_kv > 0 && max_pos > 0, NV_ERR_INVALID_ARG,
                "nv_attn_decode_paged_fused: bad sizes B=%d H_kv=%d max_pos=%lld", B, H_kv, (long long)max_pos);
@@ -1463,7 +1502,22 @@ extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const vo
     f.eps = eps;
     return decode_launch(q, k_cache, v_cache, o, nullptr, cu_seqlens_k, block_tables, B, max_blocks, max_seqlen_k,
                          H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t, workspace,
-                         workspace_bytes, false, stream, &f);
+                         workspace_bytes, false, stream, &f, chunk_keys);
+}
+
+extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w, const void* k_w,
+                                          const float* cos_sin, const int64_t* positions,
+                                          const int32_t* slot_mapping, void* k_cache, void* v_cache, void* o,
+                                          const int32_t* cu_seqlens_k, const int32_t* block_tables, int B,
+                                          int max_blocks, int max_seqlen_k, int H_q, int H_kv, int D,
+                                          int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
+                                          int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
+                                          int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+    return nv_attn_decode_paged_fused_chunked(q, k, v, q_w, k_w, cos_sin, positions, slot_mapping, k_cache, v_cache, o,
+                                              cu_seqlens_k, block_tables, B, max_blocks, max_seqlen_k, H_q, H_kv, D,
+                                              num_blocks, block_size, max_pos, eps, scale, q_stride_t, k_stride_t,
+                                              v_stride_t, o_stride_t, workspace, workspace_bytes, 0, stream);
 }
 
 extern "C" int64_t nv_attn_decode_static_scratch_bytes(void) {

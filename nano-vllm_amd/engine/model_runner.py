@@ -45,7 +45,7 @@ def _prepare_decode_inputs(seqs: list[Sequence], block_size: int) -> dict:
     return dict(input_ids=input_ids, positions=positions, slot_mapping=slots.astype(np.int32), cu_seqlens_q=cu_q,
                 cu_seqlens_k=cu_k, max_seqlen_q=1, max_seqlen_k=int(start.max()) + 1, block_tables=tables,
                 num_decode_seqs=B, num_leading_decode=B, max_seqlen_k_decode=int(start.max()) + 1,
-                max_seqlen_q_rest=0, max_seqlen_k_rest=0)
+                max_seqlen_q_rest=0, max_seqlen_k_rest=0, sum_seqlen_k_decode=int(cu_k[-1]))
 
 
 def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool = True) -> dict:
@@ -92,15 +92,16 @@ def prepare_inputs(seqs: list[Sequence], block_size: int, decode_fast_path: bool
                 num_decode_seqs=n_decode, num_leading_decode=lead,
                 max_seqlen_k_decode=int(n_k[:lead].max()) if lead else 0,
                 max_seqlen_q_rest=int(n_q[lead:].max()) if lead < len(seqs) else 0,
-                max_seqlen_k_rest=int(n_k[lead:].max()) if lead < len(seqs) else 0)
+                max_seqlen_k_rest=int(n_k[lead:].max()) if lead < len(seqs) else 0,
+                sum_seqlen_k_decode=int(cu_k[lead]))
 
 
 class _DecodeGraph:
     """A captured decode step for one (padded batch, padded table width) shape with its static buffers."""
 
-    def __init__(self, runner: "ModelRunner", batch: int, width: int):
+    def __init__(self, runner: "ModelRunner", batch: int, width: int, chunk_keys: int = 0):
         dev = runner.device
-        self.batch, self.width = batch, width
+        self.batch, self.width, self.chunk_keys = batch, width, chunk_keys
         # All per-step metadata lives in ONE device buffer with a pinned host mirror, so a step is one
         # host-to-device copy: [input_ids i64 x B | positions i64 x B | slot_mapping i32 x B |
         # cu_seqlens_k i32 x (B+1) | block_tables i32 x B*W], every section 8-byte aligned.
@@ -139,7 +140,7 @@ class _DecodeGraph:
                                 cu_seqlens_q=self.cu_seqlens_q, cu_seqlens_k=self.cu_seqlens_k, max_seqlen_q=1,
                                 max_seqlen_k=width * runner.block_size, block_tables=self.block_tables,
                                 block_size=runner.block_size, num_decode_seqs=batch, num_leading_decode=batch,
-                                max_seqlen_k_decode=width * runner.block_size)
+                                max_seqlen_k_decode=width * runner.block_size, decode_chunk_keys=chunk_keys)
         set_context(self.ctx)
         # warm-up on a side stream (library initialisation must not happen inside the capture)
         side = torch.cuda.Stream(device=dev)
@@ -206,7 +207,7 @@ class ModelRunner:
             if dist.get_backend(self.group) != "nccl":
                 raise ValueError("use_graphs with a head-sharded model needs the RCCL ('nccl') backend: the per-layer "
                                  f"all-gather of backend {dist.get_backend(self.group)!r} cannot be captured in a HIP graph")
-        self._graphs: dict[tuple[int, int], _DecodeGraph] = {}
+        self._graphs: dict[tuple[int, int, int], _DecodeGraph] = {}
 
     # ---- KV cache -------------------------------------------------------------------------
     def block_bytes(self) -> int:
@@ -255,9 +256,22 @@ class ModelRunner:
                            max_seqlen_k=m["max_seqlen_k"], block_tables=self._to_device(m["block_tables"]),
                            block_size=self.block_size, num_decode_seqs=m["num_decode_seqs"],
                            num_leading_decode=m["num_leading_decode"], max_seqlen_k_decode=m["max_seqlen_k_decode"],
-                           max_seqlen_q_rest=m["max_seqlen_q_rest"], max_seqlen_k_rest=m["max_seqlen_k_rest"])
+                           max_seqlen_q_rest=m["max_seqlen_q_rest"], max_seqlen_k_rest=m["max_seqlen_k_rest"],
+                           decode_chunk_keys=self._decode_chunk(m, m["max_seqlen_k_decode"]))
         set_context(ctx)
         return self._to_device(m["input_ids"]), self._to_device(m["positions"]), m
+
+    def _decode_chunk(self, m: dict, max_k: int) -> int:
+        """Keys per decode work item for this step's decode rows (0 = the launch plan's choice): the runner knows
+        every length, the launch plan only `max_k`, so a few long sequences among many short ones are cut finer."""
+        nd = m["num_leading_decode"]
+        if self.device.type != "cuda" or not nd:
+            return 0
+        from .. import ops
+        c = self.cfg
+        shard = getattr(self.model, "shard", None)
+        hq = shard.local_heads if shard is not None else c.num_attention_heads
+        return ops.decode_suggest_chunk(nd, hq, self.local_kv_heads, max_k, m["sum_seqlen_k_decode"])
 
     def _sample(self, logits: torch.Tensor, temperatures: list[float]) -> torch.Tensor:
         tokens = sample(logits, temperatures)
@@ -266,7 +280,7 @@ class ModelRunner:
             tokens = broadcast_tokens(tokens, self.group)      # rank 0's draw; argmax is identical everywhere
         return tokens
 
-    def _graph_for(self, n_seqs: int, table_width: int) -> _DecodeGraph:
+    def _graph_for(self, n_seqs: int, table_width: int, m: dict | None = None) -> _DecodeGraph:
         # batch buckets: 1, 2, 4, 8, then multiples of 16 (the kernels plan their launch from the padded
         # batch, so padding a small batch to 16 would halve its useful waves)
         batch = 1 << max(0, int(n_seqs - 1).bit_length()) if n_seqs <= 8 else -(-n_seqs // 16) * 16
@@ -275,15 +289,22 @@ class ModelRunner:
         p2 = 1 << max(0, int(table_width - 1).bit_length())
         step = max(1, p2 // 8)
         width = p2 if p2 <= 8 else -(-table_width // step) * step
-        g = self._graphs.get((batch, width))
+        # the launch plan is frozen into the capture: a skewed batch (a few long sequences among many short ones)
+        # gets a capture of its own, planned with the chunk suggested for it -- rounded to a power of two so that
+        # steps of similar skew share one capture (a suggestion is valid for any lengths the width holds)
+        chunk = self._decode_chunk(m, width * self.block_size) if m is not None else 0
+        if chunk:
+            chunk = 1 << int(chunk - 1).bit_length()
+        g = self._graphs.get((batch, width, chunk))
         if g is None:
             # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
             # costs two eager forwards): only capture when nothing within 25 % exists
-            fits = [k for k in self._graphs if k[1] == width and batch <= k[0] <= batch + max(16, batch // 4)]
+            fits = [k for k in self._graphs
+                    if k[1] == width and k[2] == chunk and batch <= k[0] <= batch + max(16, batch // 4)]
             if fits:
                 g = self._graphs[min(fits)]
             else:
-                g = self._graphs[(batch, width)] = _DecodeGraph(self, batch, width)
+                g = self._graphs[(batch, width, chunk)] = _DecodeGraph(self, batch, width, chunk)
         return g
 
     @torch.inference_mode()
@@ -303,7 +324,7 @@ class ModelRunner:
         ids[ids < 0] = 0                                    # placeholders never reach the embedding
         prev_tokens = prev["tokens"] if prev is not None else None
         if self.use_graphs:
-            g = self._graph_for(len(seqs), m["block_tables"].shape[1])
+            g = self._graph_for(len(seqs), m["block_tables"].shape[1], m)
             set_context(g.ctx)
             logits = g.replay(m, src if prev is not None else None, prev_tokens)
         else:
@@ -336,7 +357,7 @@ class ModelRunner:
         sequence's prompt is still being chunked or its K/V is being recomputed (model_runner.py:214-240)."""
         if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
             m = prepare_inputs(seqs, self.block_size)
-            g = self._graph_for(len(seqs), m["block_tables"].shape[1])
+            g = self._graph_for(len(seqs), m["block_tables"].shape[1], m)
             set_context(g.ctx)
             logits = g.replay(m)
         else:

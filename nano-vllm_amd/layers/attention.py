@@ -71,10 +71,11 @@ class Attention(nn.Module):
         """Attention of q against the cache as described by the current context (no store)."""
         ctx = get_context()
         B = ctx.cu_seqlens_q.numel() - 1
+        chunk = getattr(ctx, "decode_chunk_keys", 0) or 0      # (a context of the reference's class has no such field)
         if ctx.max_seqlen_q <= 1:
             return ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k,
                                          ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
-                                         cu_seqlens_q=ctx.cu_seqlens_q)
+                                         cu_seqlens_q=ctx.cu_seqlens_q, chunk_keys=chunk)
         if ctx.num_leading_decode is None and ctx.num_decode_seqs is None:
             _derive_hints(ctx)
         nd = ctx.num_leading_decode
@@ -85,7 +86,7 @@ class Attention(nn.Module):
             if nd > 0:
                 ops.attn_decode_paged(q, self.k_cache, self.v_cache, ctx.cu_seqlens_k[:nd + 1],
                                       ctx.block_tables[:nd], ctx.max_seqlen_k_decode, self.attn_scale,
-                                      cu_seqlens_q=ctx.cu_seqlens_q[:nd + 1], out=o)
+                                      cu_seqlens_q=ctx.cu_seqlens_q[:nd + 1], out=o, chunk_keys=chunk)
             if nd < B:
                 ops.attn_prefill_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q[nd:], ctx.cu_seqlens_k[nd:],
                                         ctx.block_tables[nd:], ctx.max_seqlen_q_rest, ctx.max_seqlen_k_rest,

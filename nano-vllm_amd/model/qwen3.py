@@ -106,7 +106,8 @@ def _hip_fused_decode(positions, q, k, v, q_w, k_w, rope, eps, attn):
         return None
     return ops.attn_decode_paged_fused(positions, q, k, v, q_w, k_w, rope.cos_sin_cache, eps, ctx.slot_mapping,
                                        attn.k_cache, attn.v_cache, ctx.cu_seqlens_k, ctx.block_tables,
-                                       ctx.max_seqlen_k, attn.attn_scale)
+                                       ctx.max_seqlen_k, attn.attn_scale,
+                                       chunk_keys=getattr(ctx, "decode_chunk_keys", 0) or 0)
 
 
 class Qwen3Attention(nn.Module):

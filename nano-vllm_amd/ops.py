@@ -95,8 +95,9 @@ def _attn_common(q, k_cache, v_cache, cu_seqlens_k, block_tables):
 def attn_decode_paged(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                       cu_seqlens_k: torch.Tensor, block_tables: torch.Tensor, max_seqlen_k: int,
                       scale: float, cu_seqlens_q: Optional[torch.Tensor] = None,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Paged decode attention; sequences with seqlen_q != 1 are left untouched in ``out``."""
+                      out: Optional[torch.Tensor] = None, chunk_keys: int = 0) -> torch.Tensor:
+    """Paged decode attention; sequences with seqlen_q != 1 are left untouched in ``out``.
+    `chunk_keys` > 0: the host's choice of keys per work item (`decode_suggest_chunk`), 0 = the plan's."""
     B = _attn_common(q, k_cache, v_cache, cu_seqlens_k, block_tables)
     nb, bs, hkv, d = k_cache.shape
     hq = q.shape[1]
@@ -112,16 +113,24 @@ def attn_decode_paged(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         _rows_ok(out, "out")
         _need(out.shape == q.shape, "out shape != q shape")
     dll = _lib.lib()
-    need = dll.nv_attn_decode_workspace_bytes(B, hq, hkv, d, int(max_seqlen_k))
+    need = dll.nv_attn_decode_workspace_bytes_chunked(B, hq, hkv, d, int(max_seqlen_k), int(chunk_keys))
     ws = _workspace(q.device, need)
-    rc = dll.nv_attn_decode_paged(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
-                                  cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
-                                  cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B,
-                                  block_tables.shape[1], int(max_seqlen_k), hq, hkv, d, nb, bs,
-                                  float(scale), q.stride(0), out.stride(0), ws.data_ptr(), ws.numel(),
-                                  _stream(q))
-    _lib.check(rc, "nv_attn_decode_paged")
+    rc = dll.nv_attn_decode_paged_chunked(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
+                                          cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
+                                          cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B,
+                                          block_tables.shape[1], int(max_seqlen_k), hq, hkv, d, nb, bs,
+                                          float(scale), q.stride(0), out.stride(0), ws.data_ptr(), ws.numel(),
+                                          int(chunk_keys), _stream(q))
+    _lib.check(rc, "nv_attn_decode_paged_chunked")
     return out
+
+
+def decode_suggest_chunk(num_seqs: int, hq: int, hkv: int, max_seqlen_k: int, sum_seqlen_k: int) -> int:
+    """Keys per decode work item for a batch whose lengths the host knows (0 = the plan's own choice stands):
+    a few long sequences among many short ones are cut into pieces of about a mean sequence, so that their
+    waves do not end the launch long after the others."""
+    return int(_lib.lib().nv_attn_decode_suggest_chunk(int(num_seqs), int(hq), int(hkv), int(max_seqlen_k),
+                                                       int(sum_seqlen_k)))
 
 
 def attn_prefill_varlen(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
@@ -165,7 +174,7 @@ def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.T
                             cos_sin: torch.Tensor, eps: float, slot_mapping: torch.Tensor,
                             k_cache: torch.Tensor, v_cache: torch.Tensor, cu_seqlens_k: torch.Tensor,
                             block_tables: torch.Tensor, max_seqlen_k: int, scale: float,
-                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            out: Optional[torch.Tensor] = None, chunk_keys: int = 0) -> torch.Tensor:
     """A pure decode step's q/k-norm + rotary + KV scatter + paged attention in one launch (token b is
     sequence b's only new token).  Bit-identical to qknorm_rope_store followed by attn_decode_paged."""
     _rope_common(positions, q, k, cos_sin)
@@ -191,17 +200,17 @@ def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.T
         _rows_ok(out, "out")
         _need(out.shape == q.shape, "out shape != q shape")
     dll = _lib.lib()
-    need = dll.nv_attn_decode_workspace_bytes(B, hq, hkv, d, int(max_seqlen_k))
+    need = dll.nv_attn_decode_workspace_bytes_chunked(B, hq, hkv, d, int(max_seqlen_k), int(chunk_keys))
     ws = _workspace(q.device, need)
-    rc = dll.nv_attn_decode_paged_fused(
+    rc = dll.nv_attn_decode_paged_fused_chunked(
         q.data_ptr(), k.data_ptr(), v.data_ptr(),
         q_weight.data_ptr() if q_weight is not None else None,
         k_weight.data_ptr() if k_weight is not None else None,
         cos_sin.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
         out.data_ptr(), cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B, block_tables.shape[1],
         int(max_seqlen_k), hq, hkv, d, nb, bs, cos_sin.shape[0], float(eps), float(scale),
-        q.stride(0), k.stride(0), v.stride(0), out.stride(0), ws.data_ptr(), ws.numel(), _stream(q))
-    _lib.check(rc, "nv_attn_decode_paged_fused")
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), ws.data_ptr(), ws.numel(), int(chunk_keys), _stream(q))
+    _lib.check(rc, "nv_attn_decode_paged_fused_chunked")
     return out
 
 

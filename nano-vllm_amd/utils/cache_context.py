@@ -46,6 +46,10 @@ class CacheContext:
     max_seqlen_k_decode: int = 0
     max_seqlen_q_rest: int = 0
     max_seqlen_k_rest: int = 0
+    # Extension (optional): keys per decode work item chosen by a host that knows the batch's lengths
+    # (`ops.decode_suggest_chunk`: a few long sequences among many short ones); 0 = the launch plan decides
+    # from `max_seqlen_k` alone.
+    decode_chunk_keys: int = 0
 
 
 _cache_context: ContextVar[Optional[CacheContext]] = ContextVar("CacheContext", default=None)

@@ -157,3 +157,27 @@ def test_fast_division_by_launch_constants_is_exact():
         for n in ns:
             if 0 <= n < 2 ** 31:
                 assert (n * mul) >> shr == n // d, (n, d)
+
+
+def test_decode_chunk_suggestion_known_answers():
+    """nv_attn_decode_suggest_chunk is host arithmetic (no GPU): balanced batches and launches with few
+    (sequence, kv head) pairs keep the plan's choice (0); a few long sequences among many short ones get pieces of
+    about three quarters of a mean sequence, at most 32 ranges per sequence."""
+    dll = _lib.lib()
+    f = dll.nv_attn_decode_suggest_chunk
+    assert f(256, 16, 8, 767, 256 * 640) == 0                      # the benchmark batch: longest = 1.2 x mean
+    assert f(256, 16, 8, 2048, 256 * 2048) == 0                    # uniform long sequences: no cut wanted
+    assert f(256, 16, 8, 1023, 256 * 640) == 0                     # 1.6 x the mean but only 383 keys beyond it
+    assert f(8, 32, 8, 32768, 8 * 32768) == 0 and f(1, 32, 8, 32768, 32768) == 0     # few pairs: the plan splits already
+    assert f(257, 16, 8, 8192, 256 * 640 + 8192) == 512            # mean 670 -> 0.75 x, rounded up to 64
+    assert f(257, 16, 8, 32768, 256 * 640 + 32768) == 1024         # 576 would need 57 ranges: 32 at most
+    assert f(264, 16, 8, 2048, 256 * 256 + 8 * 2048) == 256        # never below 256 keys
+    assert f(257, 64, 8, 8192, 256 * 640 + 8192) == 1024           # the MFMA-score kernels: pieces twice as long
+    assert f(0, 16, 8, 100, 100) == 0 and f(4, 16, 8, 0, 0) == 0 and f(4, 16, 5, 100, 100) == 0
+    # the workspace of a hinted launch covers its ranges; an unsplit launch needs the 16-byte minimum
+    w = dll.nv_attn_decode_workspace_bytes_chunked
+    assert w(257, 16, 8, 128, 8192, 0) == dll.nv_attn_decode_workspace_bytes(257, 16, 8, 128, 8192)
+    assert w(257, 16, 8, 128, 8192, 512) > w(257, 16, 8, 128, 8192, 0) > 16
+    assert w(256, 16, 8, 128, 767, 0) == 16 and w(256, 16, 8, 128, 500, 512) == 16
+    # a chunk is rounded up to 64 keys and never gives more than 64 ranges
+    assert w(4, 16, 8, 128, 65536, 64) == w(4, 16, 8, 128, 65536, 1024)

@@ -73,7 +73,9 @@ def _assert_out(x, y, name):
     n = int(differ.sum())
     if n == 0:
         return
-    assert n <= x.numel() // 1000, (name, "outputs differ in", n, "of", x.numel())
+    # (one value in a thousand; two values on outputs of fewer than 2000: a single contraction difference in a
+    # 256-value output is 0.4 % of it)
+    assert n <= max(2, x.numel() // 1000), (name, "outputs differ in", n, "of", x.numel())
     xf, yf = x.float()[differ], y.float()[differ]
     ulp = torch.exp2(torch.floor(torch.log2(torch.maximum(xf.abs(), yf.abs()).clamp_min(2.0 ** -126))) - 7)
     worst = ((xf - yf).abs() / ulp).max().item()

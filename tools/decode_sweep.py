@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--long", default="", help="skewed batch: comma list of COUNT:LENGTH replacing the first sequences")
+    ap.add_argument("--hint", action="store_true", help="add a row per library with the chunk nv_attn_decode_suggest_chunk gives for the batch's lengths")
     ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
     ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point),fused (one-launch step)")
     args = ap.parse_args()
@@ -44,6 +45,11 @@ def main():
     if args.variants:
         libs = {k: v for k, v in libs.items() if k in args.variants.split(",")}
     chunks = [int(c) for c in args.chunks.split(",")]
+    if args.hint:
+        hint = _lib.lib().nv_attn_decode_suggest_chunk(w.B, w.H_Q, w.H_KV, w.max_k, sum(w.ctx))
+        print(f"suggested chunk: {hint}")
+        if hint and hint not in chunks:
+            chunks.append(hint)
     stream = torch.cuda.current_stream(dev).cuda_stream
     ws = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
     results = {}
