@@ -81,6 +81,9 @@ class Workload:
         for count, length in long_tail:
             self.ctx[i:i + count] = [length] * count
             i += count
+        if long_tail:                    # the long ones anywhere in the batch
+            order = torch.randperm(batch, generator=g).tolist()
+            self.ctx = [self.ctx[j] for j in order]
         blocks = [math.ceil(c / self.BS) for c in self.ctx]
         self.NB = sum(blocks)
         perm = torch.randperm(self.NB, generator=g).tolist()

@@ -87,6 +87,8 @@ struct DecodeParams {
     int* tickets; // [B, H_kv] arrival counters of the in-launch combine (zero before the launch), or null
     int B, max_blocks, H_kv, block_size;
     int chunk, nsplit;
+    int group_items;  // work items per key-range group of the grid (B * H_kv, rounded up to whole workgroups)
+    int group_rot;    // items by which each group is rotated against the one before it
     int G;  // query heads per kv head
     int64_t num_blocks;
     int64_t q_stride_vec, o_stride_vec;
@@ -324,14 +326,24 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     // item -> (b, split, h), h fastest: the waves of a workgroup read neighbouring head
     // rows of the same tokens, i.e. whole contiguous cache rows.
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
-    const int h = item % p.H_kv;
-    const int rest = item / p.H_kv;
-    // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
-    // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
-    // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
-    const int b = rest % p.B;
-    const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
-    if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
+    // Key-range-major: the items of the batch's LAST key range first, ..., those of range 0 last; within a range
+    // (sequence, kv head) with the head fastest.  A batch of short sequences with one long one has work in range 0
+    // only, except for that sequence: sequence-major order would put the few non-empty workgroups at a fixed stride
+    // in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between; last
+    // ranges first puts the longest sequences' extra work in flight before the bulk of the grid is dispatched.
+    // The ranges of ONE sequence would be a whole group of workgroups apart -- with a group of 8 k workgroups every
+    // range of a long sequence on the same XCD -- so each group is rotated by `group_rot` items against the one
+    // before it (the host picks 0 or one workgroup's worth, whichever makes the distance odd: the ranges then
+    // cycle through all XCDs).  No padding: a grid that fills the chip exactly keeps doing so.
+    const int grp = item / p.group_items;
+    int rest = item - grp * p.group_items;
+    const int split = p.nsplit - 1 - grp;
+    const int pairs = p.B * p.H_kv;
+    if (split < 0 || rest >= pairs) return;          // behind the grid's end / the last workgroup's spare waves
+    rest += (int)(((int64_t)grp * p.group_rot) % pairs);
+    rest = rest >= pairs ? rest - pairs : rest;
+    const int h = rest % p.H_kv;
+    const int b = rest / p.H_kv;
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     // FUSE: the token's position is read with the sequence's bounds (one scalar round trip for all three)
@@ -687,14 +699,24 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     float* xa = xch_all[wave] + 16 * G;  // [16] per-head scalars (alpha, then m, l)
 
     const int item = WGS ? (int)blockIdx.x : blockIdx.x * kDecWaves + wave;
-    const int h = item % p.H_kv;
-    const int rest = item / p.H_kv;
-    // split-major: all key ranges 0 of the batch, then all ranges 1, ...  A batch of short sequences with one long
-    // one has work in ranges 0 (and 1) only: sequence-major order would put those few workgroups at a fixed
-    // stride in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between
-    const int b = rest % p.B;
-    const int split = p.nsplit - 1 - rest / p.B;   // and the LAST ranges first: the longest sequences' extra work
-    if (split < 0) return;                         // is in flight before the bulk of the grid is dispatched
+    // Key-range-major: the items of the batch's LAST key range first, ..., those of range 0 last; within a range
+    // (sequence, kv head) with the head fastest.  A batch of short sequences with one long one has work in range 0
+    // only, except for that sequence: sequence-major order would put the few non-empty workgroups at a fixed stride
+    // in the grid -- always the same XCDs and CUs under round-robin dispatch -- with empty ones between; last
+    // ranges first puts the longest sequences' extra work in flight before the bulk of the grid is dispatched.
+    // The ranges of ONE sequence would be a whole group of workgroups apart -- with a group of 8 k workgroups every
+    // range of a long sequence on the same XCD -- so each group is rotated by `group_rot` items against the one
+    // before it (the host picks 0 or one workgroup's worth, whichever makes the distance odd: the ranges then
+    // cycle through all XCDs).  No padding: a grid that fills the chip exactly keeps doing so.
+    const int grp = item / p.group_items;
+    int rest = item - grp * p.group_items;
+    const int split = p.nsplit - 1 - grp;
+    const int pairs = p.B * p.H_kv;
+    if (split < 0 || rest >= pairs) return;          // behind the grid's end / the last workgroup's spare waves
+    rest += (int)(((int64_t)grp * p.group_rot) % pairs);
+    rest = rest >= pairs ? rest - pairs : rest;
+    const int h = rest % p.H_kv;
+    const int b = rest / p.H_kv;
 
     const int n_k = p.cu_k[b + 1] - p.cu_k[b];
     int tq = b;
@@ -1185,8 +1207,18 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
     const DecodePlan d = plan_decode(B, H_kv, max_seqlen_k, H_q / H_kv);
     const long long bh = (long long)B * H_kv;
     const long long target = d.mfma ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES;
-    if (bh < target) return 0;                 // few pairs: the plan splits for occupancy already
     const long long mean = (sum_seqlen_k + B - 1) / B;
+    if (bh < target) {
+        // Few pairs: the plan cuts every sequence into max / chunk ranges so that the launch has about `target`
+        // waves -- which it only reaches when the sequences are equally long (the short ones of an uneven batch
+        // have one range each).  With the sum known: as many keys per work item as make the launch full.
+        const long long unit = d.wgs ? 64 * kDecWaves : 64;
+        const long long items = d.wgs ? target / kDecWaves : target;
+        long long chunk = (sum_seqlen_k * H_kv / items + unit - 1) / unit * unit;
+        const long long least = d.wgs ? 512 : 256;
+        if (chunk < least) chunk = least;
+        return chunk * 4 <= (long long)d.chunk * 3 ? (int)chunk : 0;      // only when it is a real change
+    }
     // balanced enough: the longest sequence within 1.4 x the mean, or less than 512 keys beyond it (a split
     // costs a merge launch and partial states: about 6 us)
     if ((long long)max_seqlen_k * 5 < mean * 7 || max_seqlen_k - mean < 512) return 0;
@@ -1318,10 +1350,15 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
             }
         }
     }
-    const int64_t items = (int64_t)B * p.nsplit * H_kv;
     const bool wgs = plan.wgs, lean = plan.lean, use_mfma = plan.mfma, mfma_deep = plan.mfma_deep;
-    NV_REQUIRE(items < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
-    const unsigned grid = wgs ? (unsigned)items : (unsigned)((items + kDecWaves - 1) / kDecWaves);
+    // workgroups per key-range group; an even count gets a rotation of one workgroup per group (see the kernels'
+    // item mapping)
+    const int64_t group_wgs = wgs ? (int64_t)B * H_kv : ((int64_t)B * H_kv + kDecWaves - 1) / kDecWaves;
+    const int64_t grid64 = group_wgs * p.nsplit;
+    NV_REQUIRE(grid64 * kDecWaves < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
+    p.group_items = (int)(wgs ? group_wgs : group_wgs * kDecWaves);
+    p.group_rot = (p.nsplit > 1 && group_wgs % 2 == 0) ? (wgs ? 1 : kDecWaves) : 0;
+    const unsigned grid = (unsigned)grid64;
     const bool aligned = block_size % 16 == 0 && p.chunk % 64 == 0;
     // the in-launch combine lives in instantiations of its own (TK): the default kernels carry none of it
 #define NV_DEC_LAUNCH3(GG, AL, TK)                                                                  \

@@ -168,7 +168,11 @@ def test_decode_chunk_suggestion_known_answers():
     assert f(256, 16, 8, 767, 256 * 640) == 0                      # the benchmark batch: longest = 1.2 x mean
     assert f(256, 16, 8, 2048, 256 * 2048) == 0                    # uniform long sequences: no cut wanted
     assert f(256, 16, 8, 1023, 256 * 640) == 0                     # 1.6 x the mean but only 383 keys beyond it
-    assert f(8, 32, 8, 32768, 8 * 32768) == 0 and f(1, 32, 8, 32768, 32768) == 0     # few pairs: the plan splits already
+    # few (sequence, kv head) pairs: the plan cuts every sequence max / chunk ways to fill the launch, which only
+    # equal lengths do; with the sum known the chunk is what fills it
+    assert f(8, 32, 8, 32768, 8 * 32768) == 0 and f(1, 32, 8, 32768, 32768) == 0
+    assert f(8, 32, 8, 32768, 7 * 1024 + 32768) == 320
+    assert f(32, 16, 8, 16384, 31 * 500 + 16384) == 256
     assert f(257, 16, 8, 8192, 256 * 640 + 8192) == 512            # mean 670 -> 0.75 x, rounded up to 64
     assert f(257, 16, 8, 32768, 256 * 640 + 32768) == 1024         # 576 would need 57 ranges: 32 at most
     assert f(264, 16, 8, 2048, 256 * 256 + 8 * 2048) == 256        # never below 256 keys
