@@ -290,11 +290,12 @@ class ModelRunner:
         step = max(1, p2 // 8)
         width = p2 if p2 <= 8 else -(-table_width // step) * step
         # the launch plan is frozen into the capture: a skewed batch (a few long sequences among many short ones)
-        # gets a capture of its own, planned with the chunk suggested for it -- rounded to a power of two so that
+        # gets a capture of its own, planned with the chunk suggested for it -- rounded up to a power of two or 1.5 x one so that
         # steps of similar skew share one capture (a suggestion is valid for any lengths the width holds)
         chunk = self._decode_chunk(m, width * self.block_size) if m is not None else 0
         if chunk:
-            chunk = 1 << int(chunk - 1).bit_length()
+            p2 = 1 << int(chunk - 1).bit_length()           # next of 256, 384, 512, 768, 1024, ...
+            chunk = p2 * 3 // 4 if chunk <= p2 * 3 // 4 else p2
         g = self._graphs.get((batch, width, chunk))
         if g is None:
             # a captured graph for a slightly larger batch serves (padded rows cost little; a capture
