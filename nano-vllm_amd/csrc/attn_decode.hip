@@ -340,7 +340,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_kernel(const Decod
     const int split = p.nsplit - 1 - grp;
     const int pairs = p.B * p.H_kv;
     if (split < 0 || rest >= pairs) return;          // behind the grid's end / the last workgroup's spare waves
-    rest += (int)(((int64_t)grp * p.group_rot) % pairs);
+    rest += (int)((unsigned)(grp * p.group_rot) % (unsigned)pairs);   // (grp < 2^31 / 4 items: no overflow)
     rest = rest >= pairs ? rest - pairs : rest;
     const int h = rest % p.H_kv;
     const int b = rest / p.H_kv;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void attn_decode_mfma_kernel(const 
     const int split = p.nsplit - 1 - grp;
     const int pairs = p.B * p.H_kv;
     if (split < 0 || rest >= pairs) return;          // behind the grid's end / the last workgroup's spare waves
-    rest += (int)(((int64_t)grp * p.group_rot) % pairs);
+    rest += (int)((unsigned)(grp * p.group_rot) % (unsigned)pairs);   // (grp < 2^31 / 4 items: no overflow)
     rest = rest >= pairs ? rest - pairs : rest;
     const int h = rest % p.H_kv;
     const int b = rest / p.H_kv;
@@ -1357,7 +1357,10 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     const int64_t grid64 = group_wgs * p.nsplit;
     NV_REQUIRE(grid64 * kDecWaves < (1LL << 31), NV_ERR_UNSUPPORTED, "nv_attn_decode_paged: launch too large");
     p.group_items = (int)(wgs ? group_wgs : group_wgs * kDecWaves);
-    p.group_rot = (p.nsplit > 1 && group_wgs % 2 == 0) ? (wgs ? 1 : kDecWaves) : 0;
+    // ... when the host has said that the batch is uneven (a chunk of its choice): with equal sequences nothing
+    // sits on one XCD for long, and every (sequence, head group) staying on one XCD measured 1 - 1.5 % faster
+    // (8 x 32 k keys: 176.5 against 179.5 us; its block table and query rows stay in that XCD's L2)
+    p.group_rot = (chunk_keys > 0 && p.nsplit > 1 && group_wgs % 2 == 0) ? (wgs ? 1 : kDecWaves) : 0;
     const unsigned grid = (unsigned)grid64;
     const bool aligned = block_size % 16 == 0 && p.chunk % 64 == 0;
     // the in-launch combine lives in instantiations of its own (TK): the default kernels carry none of it
