@@ -114,7 +114,7 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  *   nv_attn_decode_suggest_chunk: keys per work item for a batch with this sum of lengths, or 0 when the
  *     plan's own choice stands (balanced batches, launches with few (sequence, kv head) pairs).
  *   nv_attn_decode_paged_chunked / nv_attn_decode_paged_fused_chunked: the entry points above with that value
- *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 64 ranges per sequence).
+ *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 256 ranges per sequence).
  *     Results equal the unhinted launch's up to the fp32 summation order of the merge.
  *   nv_attn_decode_workspace_bytes_chunked: the workspace such a launch needs.
  * Sequences of at most chunk keys are written by the attention launch directly, whatever the others need.

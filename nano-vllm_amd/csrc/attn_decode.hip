@@ -1146,10 +1146,10 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G, int chunk_keys 
     if (tn.decode_chunk > 0) {
         d.chunk = tn.decode_chunk;
     } else if (chunk_keys > 0) {
-        // a multiple of 64 keys (of 256 for workgroup items), and at most 64 ranges per sequence
+        // a multiple of 64 keys (of 256 for workgroup items), and at most 256 ranges per sequence
         const long long unit = d.wgs ? 64 * kDecWaves : 64;
         long long chunk = ((long long)chunk_keys + unit - 1) / unit * unit;
-        const long long least = (((long long)max_k + 63) / 64 + unit - 1) / unit * unit;
+        const long long least = (((long long)max_k + 255) / 256 + unit - 1) / unit * unit;
         d.chunk = (int)(chunk < least ? least : chunk);
     } else {
         // Fewest splits that still give the launch about `target` waves; unsplit sequences are

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--hq", type=int, default=16)
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--long", default="", help="skewed batch: comma list of COUNT:LENGTH replacing the first sequences")
+    ap.add_argument("--chunk-by-call", action="store_true", help="positive chunks go in as nv_attn_decode_paged_chunked's argument instead of the process-wide override")
     ap.add_argument("--hint", action="store_true", help="add a row per library with the chunk nv_attn_decode_suggest_chunk gives for the batch's lengths")
     ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
     ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point),fused (one-launch step)")
@@ -68,7 +69,7 @@ def main():
                 fields["decode_single_launch"] = int(mode[6])
             for chunk in chunks:
                 f = dict(fields)
-                if chunk > 0:
+                if chunk > 0 and not args.chunk_by_call:
                     f["decode_chunk"] = chunk
                 elif chunk < 0:
                     f["decode_target_waves"] = -chunk
@@ -91,6 +92,8 @@ def main():
                             w.block_tables.data_ptr(), w.B, w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB,
                             w.BS, w.MAX_POS, w.EPS, w.scale, w.q_in.stride(0), w.k_in.stride(0), w.v_in.stride(0),
                             w.o.stride(0), ws.data_ptr(), ws.numel(), stream)
+                    elif args.chunk_by_call and chunk > 0:    # the host's chunk as an argument (what a runner passes)
+                        rc = dll.nv_attn_decode_paged_chunked(*args_, ws.data_ptr(), ws.numel(), chunk, stream)
                     else:
                         rc = dll.nv_attn_decode_paged(*args_, ws.data_ptr(), ws.numel(), stream)
                     assert rc == 0, dll.nv_last_error()

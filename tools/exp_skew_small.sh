@@ -1,6 +1,6 @@
 #!/bin/bash
 # decode launch on SMALL uneven batches (fewer (sequence, kv head) pairs than the launch wants waves)
-S="timeout -k 5 200 python -u tools/decode_sweep.py --rounds 5 --modes auto --layers 8 --hint"
+S="timeout -k 5 200 python -u tools/decode_sweep.py --rounds 5 --modes auto --layers 8 --hint --chunk-by-call"
 echo "== H 32/8: 7 x 1024 + 1 x 32768"; $S --hq 32 --hkv 8 --batch 8 --ctx-lo 1024 --ctx-hi 1024 --long 1:32768 --chunks 0,256,512 2>/dev/null
 echo "== H 16/8: 31 x U[300,700] + 1 x 16384"; $S --batch 32 --ctx-lo 300 --ctx-hi 700 --long 1:16384 --chunks 0,256,512 2>/dev/null
 echo "== H 32/8: 8 x 32768 (uniform)"; $S --layers 2 --hq 32 --hkv 8 --batch 8 --ctx-lo 32768 --ctx-hi 32768 --chunks 0 2>/dev/null
