@@ -448,9 +448,9 @@ def decode_skew_records(dev, iters=20):
     dll = _lib.lib()
     stream = torch.cuda.current_stream(dev).cuda_stream
     out = []
-    for label, long_tail in (("one of 8192 keys", [(1, 8192)]), ("four of 4096 keys", [(4, 4096)]),
-                             ("one of 32768 keys", [(1, 32768)])):
-        w = Workload(dev, 4, 256 + sum(c for c, _ in long_tail), 513, 767, long_tail=long_tail)
+    for n_short, label, long_tail in ((256, "one of 8192 keys", [(1, 8192)]), (256, "four of 4096 keys", [(4, 4096)]),
+                                      (256, "one of 32768 keys", [(1, 32768)]), (63, "one of 32768 keys", [(1, 32768)])):
+        w = Workload(dev, 4, n_short + sum(c for c, _ in long_tail), 513, 767, long_tail=long_tail)
         chunk = dll.nv_attn_decode_suggest_chunk(w.B, w.H_Q, w.H_KV, w.max_k, sum(w.ctx))
         ws = torch.empty(max(16, dll.nv_attn_decode_workspace_bytes_chunked(w.B, w.H_Q, w.H_KV, w.D, w.max_k, chunk),
                              dll.nv_attn_decode_workspace_bytes(w.B, w.H_Q, w.H_KV, w.D, w.max_k)),
@@ -468,7 +468,7 @@ def decode_skew_records(dev, iters=20):
         ms_plain = _time_launches(lambda l: launch(l, 0), w.L, iters, dev)
         ms_hint = _time_launches(lambda l: launch(l, chunk), w.L, iters, dev)
         nbytes = w.attn_bytes_per_launch()
-        out.append({"workload": f"256 sequences of 513..767 keys and {label}, H {w.H_Q}/{w.H_KV}, block {w.BS}",
+        out.append({"workload": f"{n_short} sequences of 513..767 keys and {label}, H {w.H_Q}/{w.H_KV}, block {w.BS}",
                     "bytes": nbytes, "ms_planned_from_max": round(ms_plain, 5), "suggested_chunk": chunk,
                     "ms_with_suggested_chunk": round(ms_hint, 5),
                     "GBps_with_suggested_chunk": round(nbytes / (ms_hint * 1e-3) / 1e9, 1)})
