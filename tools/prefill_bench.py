@@ -19,6 +19,13 @@ CASES = {
     "cfg3_chunk_last_8k": ([512], [8192], 32, 8),
     "cfg3_chunk_mid_4k": ([512], [4096], 32, 8),
     "cfg3_7seq_chunks": ([512] * 7, [512, 1024, 2048, 4096, 8192, 6144, 3072], 32, 8),
+    # the same step with its sequences ordered by key count (what a runner that holds the lengths could do)
+    "cfg3_7seq_longest_first": ([512] * 7, [8192, 6144, 4096, 3072, 2048, 1024, 512], 32, 8),
+    "cfg3_7seq_shortest_first": ([512] * 7, [512, 1024, 2048, 3072, 4096, 6144, 8192], 32, 8),
+    # uneven whole-prompt prefill (8 prompts of 256 .. 8192 tokens) in three orders
+    "uneven_full": ([1024, 256, 8192, 512, 4096, 2048, 512, 3072], [1024, 256, 8192, 512, 4096, 2048, 512, 3072], 32, 8),
+    "uneven_full_longest_first": ([8192, 4096, 3072, 2048, 1024, 512, 512, 256], [8192, 4096, 3072, 2048, 1024, 512, 512, 256], 32, 8),
+    "uneven_full_shortest_first": ([256, 512, 512, 1024, 2048, 3072, 4096, 8192], [256, 512, 512, 1024, 2048, 3072, 4096, 8192], 32, 8),
     "b16_n2048_h32": ([2048] * 16, [2048] * 16, 32, 8),
     "b4_n8192_h32": ([8192] * 4, [8192] * 4, 32, 8),
     "b16_n2048_h64": ([2048] * 16, [2048] * 16, 64, 8),
