@@ -322,6 +322,8 @@ def prefill_records(dev, iters=10, ceiling_tflops=None):
         ("last chunk of that prompt alone: 512 queries over 8192 cached keys", [([512], [8192])]),
         ("7 sequences in one step, a 512-token chunk each, cached keys 512..8192",
          [([512] * 7, [512, 1024, 2048, 4096, 8192, 6144, 3072])]),
+        ("the same 7 sequences in the row order the runner gives a step (ModelRunner.step_order: longest first)",
+         [([512] * 7, [8192, 6144, 4096, 3072, 2048, 1024, 512])]),
         ("4 sequences x 8192 tokens, whole-prompt prefill", [([8192] * 4, [8192] * 4)]),
     ]
     out = []
