@@ -208,6 +208,9 @@ class ModelRunner:
                 raise ValueError("use_graphs with a head-sharded model needs the RCCL ('nccl') backend: the per-layer "
                                  f"all-gather of backend {dist.get_backend(self.group)!r} cannot be captured in a HIP graph")
         self._graphs: dict[tuple[int, int, int], _DecodeGraph] = {}
+        # plan decode launches with the step's lengths (False: from the longest one alone, as a caller of the
+        # reference's interface would; kept as a switch for measurements)
+        self.use_length_hints = True
 
     # ---- KV cache -------------------------------------------------------------------------
     def block_bytes(self) -> int:
@@ -265,7 +268,7 @@ class ModelRunner:
         """Keys per decode work item for this step's decode rows (0 = the launch plan's choice): the runner knows
         every length, the launch plan only `max_k`, so a few long sequences among many short ones are cut finer."""
         nd = m["num_leading_decode"]
-        if self.device.type != "cuda" or not nd:
+        if self.device.type != "cuda" or not nd or not self.use_length_hints:
             return 0
         from .. import ops
         c = self.cfg

@@ -108,6 +108,29 @@ def run_long_context_decode(model_name="llama31_8b", batch=8, ctx=32768, out_len
     return s
 
 
+def run_skewed_batch(model_name="qwen3_0_6b", n_short=255, short_len=512, long_len=16384, out_len=128, device="cuda:0",
+                     seed=0, hints=True):
+    """`n_short` prompts of `short_len` tokens and ONE of `long_len`, all decoding together: the decode steps'
+    attention launch has one sequence 30 x as long as the others.  `hints`: the runner plans the launch with
+    the step's lengths (default) or from the longest one alone."""
+    cfg, model = _build(model_name, device, seed)
+    blocks = n_short * (-(-(short_len + out_len) // 256)) + (long_len + out_len) // 256 + 16
+    eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=blocks, device=device, eos=-1, use_graphs=True,
+                    pipelined_decode=True)
+    eng.runner.use_length_hints = hints
+    g = torch.Generator().manual_seed(seed)
+    warm = [torch.randint(0, cfg.vocab_size, (short_len,), generator=g).tolist() for _ in range(8)]
+    eng.generate(warm, SamplingParams(0.0, 3))
+    prompts = [torch.randint(0, cfg.vocab_size, (long_len,), generator=g).tolist()]
+    prompts += [torch.randint(0, cfg.vocab_size, (short_len,), generator=g).tolist() for _ in range(n_short)]
+    torch.cuda.synchronize()
+    outs, m = eng.generate(prompts, SamplingParams(0.0, out_len))
+    s = m.summary()
+    s.update(model=model_name, n_short=n_short, short_len=short_len, long_len=long_len, out_len=out_len,
+             length_hints=hints, decode_graphs=sorted(eng.runner._graphs))
+    return s
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3_0_6b")
@@ -118,7 +141,8 @@ if __name__ == "__main__":
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fuse-gemms", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous decode loop (token values read every step)")
-    ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode"])
+    ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode", "skewed_batch"])
+    ap.add_argument("--no-length-hints", action="store_true", help="skewed_batch: plan decode launches from the longest length alone")
     ap.add_argument("--ctx", type=int, default=32768)
     ap.add_argument("--prefill-kernel", type=int, default=-1, choices=[-1, 0, 1],
                     help="force the compiler-scheduled (0) or the hand-scheduled (1) prefill kernel; -1 = heuristic")
@@ -128,6 +152,9 @@ if __name__ == "__main__":
         _lib.set_tuning(prefill_kernel=a.prefill_kernel)
     if a.scenario == "long_prompt":
         print(json.dumps(run_long_prompt_with_shared_prefix(a.model if a.model != "qwen3_0_6b" else "qwen3_8b")))
+        sys.exit(0)
+    if a.scenario == "skewed_batch":
+        print(json.dumps(run_skewed_batch(a.model, hints=not a.no_length_hints)))
         sys.exit(0)
     if a.scenario == "long_context_decode":
         print(json.dumps(run_long_context_decode(a.model if a.model != "qwen3_0_6b" else "llama31_8b",
