@@ -2,7 +2,7 @@
 """Randomised differential run of the attention kernels against the oracle (development aid; the fixed cases live
 in tests/): random head counts, block sizes, batch compositions (decode rows, chunks, whole prompts, empty and
 one-token sequences), lengths, softmax scales and query strides; both prefill kernels, the launch plan's choice,
-forced key-range splits, both decode work-item forms and combines.  Output rows sit inside NaN guard rows.
+forced key-range splits, both decode work-item forms and combines, decode launches with the host's chunk.  Output rows sit inside NaN guard rows.
 
     python tests/fuzz_attention.py --iters 300 [--seed 0]
 """
@@ -61,6 +61,9 @@ def one(seed, verbose):
         for form in (0, 1):
             for single in (0, 1):
                 variants.append((dict(decode_work_item=form, decode_single_launch=single), "decode"))
+        # the host's choice of keys per work item (rotated grid, direct rows next to split ones)
+        for form in (-1, 0, 1):
+            variants.append((dict(decode_work_item=form), ("decode", r.choice([64, 128, 256, 320, 512, 1000, 2048]))))
     else:
         for kern in (-1, 0, 1):
             variants.append((dict(prefill_kernel=kern), "prefill"))
@@ -73,7 +76,10 @@ def one(seed, verbose):
         guard = 8
         big = torch.full((guard + T + guard, H_q, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
         o = big[guard:guard + T]
-        if mode == "decode":
+        if isinstance(mode, tuple):
+            ops.attn_decode_paged(d["q"], d["k_cache"], d["v_cache"], d["cu_k"], d["block_tables"], p["max_k"], p["scale"],
+                                  cu_seqlens_q=d["cu_q"], out=o, chunk_keys=mode[1])
+        elif mode == "decode":
             ops.attn_decode_paged(d["q"], d["k_cache"], d["v_cache"], d["cu_k"], d["block_tables"], p["max_k"], p["scale"],
                                   cu_seqlens_q=d["cu_q"], out=o)
         elif mode == "prefill":
