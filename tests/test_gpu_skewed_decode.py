@@ -138,5 +138,14 @@ def test_engine_plans_a_skewed_decode_step_with_the_hint():
     torch.cuda.synchronize()
     assert torch.isfinite(logits_g).all()
     assert (logits_g - logits_e).abs().max().item() <= 2e-2
+    # the rest of the run replays captured graphs whose chunk was chosen for other lengths of the same skew
+    seqs_all = list(batch)
+    for _ in range(64):
+        sched.update_from_output(batch, runner.run(batch))
+        if sched.is_finished():
+            break
+        batch, _ = sched.schedule()
+    assert sched.is_finished() and all(len(s.output_tokens) == 16 for s in seqs_all)
+    assert any(k[2] > 0 for k in runner._graphs)
     # a balanced batch of the same size keeps the plan's own choice
     assert runner._decode_chunk(dict(num_leading_decode=256, sum_seqlen_k_decode=256 * 640), 768) == 0
