@@ -66,9 +66,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(const PrefillParam
     const int bid = blockIdx.x - split * p.grid_base;
     const int xcd = bid & 7;
     const int slot = bid >> 3;
-    const int pair = (slot / p.wg_per_pair) * 8 + xcd;
-    if (pair >= p.n_pairs) return;
-    const int widx = slot % p.wg_per_pair;
+    const int round = slot / p.slots_per_pair;          // 8 >> xs_shift pairs per round of XCDs
+    const int pair = round * (8 >> p.xs_shift) + (xcd >> p.xs_shift);
+    const int widx = ((slot - round * p.slots_per_pair) << p.xs_shift) + (xcd & ((1 << p.xs_shift) - 1));
+    if (pair >= p.n_pairs || widx >= p.wg_per_pair) return;
     const int groups = p.wg_per_pair / p.n_qtiles;      // head groups per kv head (G / hpw)
     const int hg = widx % groups;
     const int qt = p.n_qtiles - 1 - widx / groups;      // heaviest (latest) tiles first
@@ -407,13 +408,32 @@ constexpr int kMaxItemsPerWg = NV_PF_MAX_ITEMS;   // query tiles per workgroup o
 
 static int gcd_int(int a, int b) { return b == 0 ? a : gcd_int(b, a % b); }
 
+struct PrefillShape;
+static void prefill_set_grid(PrefillShape& sh);
+
 struct PrefillShape {
     int nw, hpw, rows_per_wg, n_qtiles, wg_per_pair, n_pairs;
+    int xs_shift, slots_per_pair;   // see PrefillParams
     int64_t grid_base;
     int nsplit, tiles_per_split;
     bool hand_scheduled;   // attn_prefill_asm_kernel (64 query rows per wave, never split) instead of attn_prefill_kernel
     int items_per_wg;      // its workgroups take 1, 2 or 4 query tiles each (chosen so that all have equal work)
 };
+
+// Workgroups per key range: whole rounds of 8 XCDs; with fewer than 8 pairs each pair takes 8, 4 or 2 of them.
+static void prefill_set_grid(PrefillShape& sh) {
+    // the fullest XCD would hold over 15 % more pairs than the average (6 or 12 pairs on 8 XCDs, one on 8): spread
+    // each pair over the fewest XCDs that make the count even again (its K/V tiles are then read into that many L2s,
+    // which a compute-bound launch does not notice).  One 8192-token sequence on a one-kv-head shard 695 -> 170 us,
+    // three 4096-token sequences x 4 kv heads 457 -> 343; 7 pairs stay as they are (one idle XCD of eight costs
+    // less than the spread: 237 against 247 us)
+    sh.xs_shift = 0;
+    if (((sh.n_pairs + 7) / 8) * 8 * 20 > sh.n_pairs * 23)
+        while (sh.xs_shift < 3 && ((sh.n_pairs << sh.xs_shift) & 7) != 0) ++sh.xs_shift;
+    const int xs = 1 << sh.xs_shift, per_round = 8 >> sh.xs_shift;
+    sh.slots_per_pair = (sh.wg_per_pair + xs - 1) / xs;
+    sh.grid_base = (int64_t)((sh.n_pairs + per_round - 1) / per_round) * 8 * sh.slots_per_pair;
+}
 
 // Workgroup shape and key-range split of a launch.  The key range is split only when the
 // launch would leave most CUs without a workgroup (one long sequence prefilled in chunks)
@@ -426,7 +446,7 @@ static void prefill_grid(PrefillShape& sh, int B, int H_q, int H_kv, int max_seq
     sh.n_qtiles = (max_seqlen_q + sh.rows_per_wg - 1) / sh.rows_per_wg;
     sh.wg_per_pair = sh.n_qtiles * (G / sh.hpw);
     sh.n_pairs = B * H_kv;
-    sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+    prefill_set_grid(sh);
 }
 
 static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, int max_seqlen_k) {
@@ -474,7 +494,7 @@ static PrefillShape prefill_shape(int B, int H_q, int H_kv, int max_seqlen_q, in
                     sh.items_per_wg = m;
                     sh.wg_per_pair = slots * groups;
                     sh.n_qtiles = slots;
-                    sh.grid_base = (int64_t)((sh.n_pairs + 7) / 8) * 8 * sh.wg_per_pair;
+                    prefill_set_grid(sh);
                     break;
                 }
             }
@@ -571,6 +591,9 @@ extern "C" int nv_attn_prefill_varlen(const void* q, const void* k_cache, const 
     p.nsplit = sh.nsplit;
     p.tiles_per_split = sh.tiles_per_split;
     p.grid_base = (int)sh.grid_base;
+    p.xs_shift = sh.xs_shift;
+    p.slots_per_pair = sh.slots_per_pair;
+    p.fd_slots_per_pair = make_fastdiv((uint32_t)sh.slots_per_pair);
     p.pair_items = sh.items_per_wg;
     p.groups = sh.wg_per_pair / sh.n_qtiles;
     p.fd_wg_per_pair = make_fastdiv((uint32_t)sh.wg_per_pair);

@@ -42,10 +42,14 @@ struct PrefillParams {
     int nsplit;           // 1: results are written directly
     int tiles_per_split;  // 64-key tiles per split
     int grid_base;        // workgroups per split (multiple of 8)
+    // A pair's workgroups sit on one XCD (they share its K/V tiles through that L2) unless the launch has fewer than 8
+    // pairs: then each pair is spread over 1 << xs_shift XCDs (2, 4 or 8), or most of the chip would idle
+    // (one sequence on a one-kv-head shard ran on one XCD of eight).  slots_per_pair = ceil(wg_per_pair >> xs_shift).
+    int xs_shift, slots_per_pair;
     int pair_items;       // hand-scheduled kernel: query tiles per workgroup (1, 2 or 4; balanced over the sequence)
     // the block-index decomposition's divisors, prepared by the host (the merge launch is a few hundred instructions long)
     int groups;           // wg_per_pair / n_qtiles: head groups per kv head (G / hpw)
-    FastDiv fd_wg_per_pair, fd_groups, fd_H_kv, fd_hpw, fd_rows_per_wg;
+    FastDiv fd_wg_per_pair, fd_slots_per_pair, fd_groups, fd_H_kv, fd_hpw, fd_rows_per_wg;
 };
 
 // hand-scheduled kernel for large launches (attn_prefill_asm.hip): one wave per SIMD, 64 query rows per wave

@@ -29,6 +29,15 @@ CASES = {
     "b16_n2048_h32": ([2048] * 16, [2048] * 16, 32, 8),
     "b4_n8192_h32": ([8192] * 4, [8192] * 4, 32, 8),
     "b16_n2048_h64": ([2048] * 16, [2048] * 16, 64, 8),
+    # head shards of Qwen3-32B (64 / 8 heads over 1, 2, 4, 8 GPUs): one sequence, a 512-token chunk over 4096 keys, and a
+    # whole 8192-token prompt
+    "tp1_chunk": ([512], [4096], 64, 8), "tp2_chunk": ([512], [4096], 32, 4),
+    "tp4_chunk": ([512], [4096], 16, 2), "tp8_chunk": ([512], [4096], 8, 1),
+    "tp1_full": ([8192], [8192], 64, 8), "tp2_full": ([8192], [8192], 32, 4),
+    "tp4_full": ([8192], [8192], 16, 2), "tp8_full": ([8192], [8192], 8, 1),
+    # pair counts that do not fill the 8 XCDs evenly: 3 sequences x 4 kv heads, 7 x 1, 3 x 8
+    "pairs12_full": ([4096] * 3, [4096] * 3, 32, 4), "pairs7_full": ([4096] * 7, [4096] * 7, 8, 1),
+    "pairs24_full": ([4096] * 3, [4096] * 3, 32, 8),
     # per-workgroup cost probes: 4096 workgroups of the hand-scheduled kernel with 1 / 2 / 4 tiles each
     "wg_probe_1tile": ([64] * 512, [64] * 512, 32, 8),
     "wg_probe_2tile": ([64] * 512, [128] * 512, 32, 8),
