@@ -325,9 +325,16 @@ def prefill_records(dev, iters=10, ceiling_tflops=None):
         ("the same 7 sequences in the row order the runner gives a step (ModelRunner.step_order: longest first)",
          [([512] * 7, [8192, 6144, 4096, 3072, 2048, 1024, 512])]),
         ("4 sequences x 8192 tokens, whole-prompt prefill", [([8192] * 4, [8192] * 4)]),
+        # per-GPU shapes of config 4 (Qwen3-32B, 64 / 8 heads over 8 and 4 GPUs): one sequence has 1 or 2
+        # (sequence, kv head) pairs, whose workgroups are spread over all XCDs
+        ("one 8192-token prompt, whole-prompt prefill", [([8192], [8192])], (8, 1)),
+        ("one 8192-token prompt, whole-prompt prefill", [([8192], [8192])], (16, 2)),
+        ("last 512-token chunk of an 8192-token prompt", [([512], [8192])], (8, 1)),
     ]
     out = []
-    for label, launches in cases:
+    for case in cases:
+        label, launches = case[0], case[1]
+        H_q, H_kv = case[2] if len(case) > 2 else (32, 8)
         n_ks_all = launches[-1][1] if len(launches) > 1 else launches[0][1]
         NB, width, bt, _ = _paged_layout(n_ks_all, bs, 3, dev)
         kc = torch.randn(NB, bs, H_kv, D, device=dev).bfloat16()
@@ -354,7 +361,8 @@ def prefill_records(dev, iters=10, ceiling_tflops=None):
                     _lib.check(rc, "nv_attn_prefill_varlen")
         ms = _time_launches(run_all, 1, iters, dev)
         tf = flops / (ms * 1e-3) / 1e12
-        out.append({"workload": f"Qwen3-8B attention shapes (H {H_q}/{H_kv}, D {D}, block {bs}): {label}",
+        family = "Qwen3-8B attention shapes" if (H_q, H_kv) == (32, 8) else "Qwen3-32B head-shard shapes"
+        out.append({"workload": f"{family} (H {H_q}/{H_kv}, D {D}, block {bs}): {label}",
                     "launches": len(plans), "flops": flops, "ms": round(ms, 4), "achieved_tflops": round(tf, 1),
                     "peak": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4)})
         if ceiling_tflops:

@@ -645,6 +645,25 @@ def test_prefill_forced_key_range_split_ragged(hip, tuning, nsplit, H_q, H_kv, k
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("nsplit", [0, 3])
+@pytest.mark.parametrize("H_q,H_kv,n_seqs", [(8, 1, 1), (16, 2, 1), (8, 1, 3), (32, 4, 1), (12, 6, 1), (32, 4, 3), (16, 4, 5),
+                                             (8, 1, 7), (64, 8, 1)])
+def test_prefill_pair_counts_that_do_not_fill_the_xcds(hip, tuning, H_q, H_kv, n_seqs, nsplit, kernel):
+    """1, 2, 3, 4, 6, 12 and 20 (sequence, kv head) pairs: each pair's workgroups are spread over 8, 4 or 2 XCDs
+    (head shards of a large model with one or a few sequences in the step); 7 and 8 pairs keep one XCD per pair.
+    Ragged chunked sequences, both kernels, with and without a forced key-range split (whose merge kernel repeats
+    the workgroup decomposition)."""
+    _, ops = hip
+    n_qs = [300, 129, 64, 5, 200, 70, 257][:n_seqs]
+    n_ks = [1100, 129, 700, 261, 200, 900, 300][:n_seqs]
+    p = make_paged_problem(41 + n_seqs, n_qs, n_ks, H_q, H_kv, 256, 20)
+    ref = ref_attention.paged_attention_ref(p["q"], p["k_cache"], p["v_cache"], p["cu_q"], p["cu_k"],
+                                            p["block_tables"], p["scale"])
+    tuning(prefill_split=nsplit, prefill_kernel=kernel)
+    _attn_check(_run_attention(ops, to_dev(p), "prefill"), ref, f"pairs {n_seqs * H_kv} split {nsplit} kernel {kernel}")
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("scale", [0.0, -0.0884, 1.0, 0.003, 0.25, 0.0884 * 1.9999])
 def test_prefill_softmax_scale_values(hip, tuning, kernel, scale):
     """The hand-scheduled kernel splits scale * log2(e) into a power of two (folded into Q, exact) and a factor in
