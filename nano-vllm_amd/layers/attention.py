@@ -22,7 +22,7 @@ from .. import ops
 from ..utils.cache_context import get_context
 
 
-def _derive_hints(ctx) -> None:
+def _derive_hints(ctx, num_heads: int = 0, num_kv_heads: int = 0) -> None:
     """A caller that gave no hints (the reference's runner builds its context from host lists and passes
     only the tensors): read the two cumulative-length tensors back ONCE per step -- one small device-to-host
     copy in the first layer of a step that mixes decode rows and prompt chunks; pure decode steps never get
@@ -39,6 +39,10 @@ def _derive_hints(ctx) -> None:
     ctx.max_seqlen_q_rest = max(n_q[nd:], default=0)
     ctx.max_seqlen_k_rest = max(n_k[nd:], default=0)
     ctx.num_decode_seqs = sum(1 for n in n_q if n == 1)
+    # the lengths are on the host now: the decode rows' launch can be planned with them (see ops.decode_suggest_chunk)
+    if nd and num_heads and num_kv_heads and not getattr(ctx, "decode_chunk_keys", 0):
+        ctx.decode_chunk_keys = ops.decode_suggest_chunk(nd, num_heads, num_kv_heads, ctx.max_seqlen_k_decode,
+                                                         sum(n_k[:nd]))
 
 
 class Attention(nn.Module):
@@ -77,7 +81,8 @@ class Attention(nn.Module):
                                          ctx.block_tables, ctx.max_seqlen_k, self.attn_scale,
                                          cu_seqlens_q=ctx.cu_seqlens_q, chunk_keys=chunk)
         if ctx.num_leading_decode is None and ctx.num_decode_seqs is None:
-            _derive_hints(ctx)
+            _derive_hints(ctx, self.num_heads, self.num_kv_heads)
+            chunk = getattr(ctx, "decode_chunk_keys", 0) or 0
         nd = ctx.num_leading_decode
         if nd is not None:
             # decode rows lead the batch: each kernel gets exactly its own sequences (no idle

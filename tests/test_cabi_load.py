@@ -185,3 +185,19 @@ def test_decode_chunk_suggestion_known_answers():
     assert w(256, 16, 8, 128, 767, 0) == 16 and w(256, 16, 8, 128, 500, 512) == 16
     # a chunk is rounded up to 64 keys and never gives more than 256 ranges
     assert w(4, 16, 8, 128, 65536, 64) == w(4, 16, 8, 128, 65536, 256) < w(4, 16, 8, 128, 65536, 0) * 9
+
+
+def test_derived_hints_include_the_decode_chunk_of_a_skewed_mixed_step():
+    """Once the lengths are on the host (a mixed step of a runner that gave no hints), the decode rows' launch is
+    planned with them: 256 decode rows of ~640 keys and one of 8192, followed by a prompt chunk."""
+    from nanovllm_amd.layers.attention import _derive_hints
+    n_k = [640] * 256 + [8192] + [512]
+    n_q = [1] * 257 + [512]
+    cu = lambda xs: torch.tensor([0] + torch.tensor(xs).cumsum(0).tolist(), dtype=torch.int32)
+    ctx = nanovllm_amd.CacheContext(cu_seqlens_q=cu(n_q), cu_seqlens_k=cu(n_k), max_seqlen_q=512, max_seqlen_k=8192)
+    _derive_hints(ctx, 16, 8)
+    assert ctx.num_leading_decode == 257 and ctx.max_seqlen_k_decode == 8192 and ctx.decode_chunk_keys == 512
+    even = nanovllm_amd.CacheContext(cu_seqlens_q=cu(n_q), cu_seqlens_k=cu([640] * 257 + [512]), max_seqlen_q=512,
+                                     max_seqlen_k=640)
+    _derive_hints(even, 16, 8)
+    assert even.decode_chunk_keys == 0
