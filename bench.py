@@ -472,7 +472,7 @@ def decode_skew_records(dev, iters=20):
                                                   w.cu_k.data_ptr(), w.block_tables.data_ptr(), w.B,
                                                   w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB, w.BS,
                                                   w.scale, w.q_rot.stride(0), w.o.stride(0), ws.data_ptr(), ws.numel(),
-                                                  ck, stream)
+                                                  ck, 0, stream)
             if rc != 0:
                 _lib.check(rc, "nv_attn_decode_paged_chunked")
         ms_plain = _time_launches(lambda l: launch(l, 0), w.L, iters, dev)

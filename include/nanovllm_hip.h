@@ -114,11 +114,18 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  *   nv_attn_decode_suggest_chunk: keys per work item for a batch with this sum of lengths, or 0 when the
  *     plan's own choice stands (balanced batches, launches with few (sequence, kv head) pairs).
  *   nv_attn_decode_paged_chunked / nv_attn_decode_paged_fused_chunked: the entry points above with that value
- *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 256 ranges per sequence).
+ *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 256 ranges per sequence)
+ *     and flags (0, or NV_DECODE_WS_COUNTERS_ZERO below).
  *     Results equal the unhinted launch's up to the fp32 summation order of the merge.
  *   nv_attn_decode_workspace_bytes_chunked: the workspace such a launch needs.
  * Sequences of at most chunk keys are written by the attention launch directly, whatever the others need.
  */
+/* flags of the _chunked entry points.  NV_DECODE_WS_COUNTERS_ZERO: the caller vouches that the first 64 KiB of the
+ * workspace (the arrival counters of the in-launch combine) are zero and that nothing but this library's decode
+ * launches, ordered on one stream, writes the workspace: launches with at most 8 (sequence, kv head) pairs then
+ * combine their key ranges inside the launch, with no second kernel (the launch puts the counters back to zero).
+ * One sequence of 1024 keys at 16 / 8 heads: 9.3 us against 14.4 with the merge launch. */
+#define NV_DECODE_WS_COUNTERS_ZERO 1
 NV_API int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_seqlen_k, int64_t sum_seqlen_k);
 NV_API int64_t nv_attn_decode_workspace_bytes_chunked(int B, int H_q, int H_kv, int D, int max_seqlen_k,
                                                       int chunk_keys);
@@ -128,7 +135,8 @@ NV_API int nv_attn_decode_paged_chunked(const void* q, const void* k_cache, cons
                                         int max_seqlen_k, int H_q, int H_kv, int D,
                                         int64_t num_blocks, int block_size, float scale,
                                         int64_t q_stride_t, int64_t o_stride_t,
-                                        void* workspace, int64_t workspace_bytes, int chunk_keys, void* stream);
+                                        void* workspace, int64_t workspace_bytes, int chunk_keys, int flags,
+                                        void* stream);
 
 /*
  * nv_attn_decode_paged without a workspace argument, for callers that cannot allocate device memory
@@ -278,7 +286,7 @@ NV_API int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, cons
                                int64_t num_blocks, int block_size, int64_t max_pos, float eps, float scale,
                                int64_t q_stride_t, int64_t k_stride_t, int64_t v_stride_t,
                                int64_t o_stride_t, void* workspace, int64_t workspace_bytes, int chunk_keys,
-                               void* stream);
+                               int flags, void* stream);
 
 #ifdef __cplusplus
 }

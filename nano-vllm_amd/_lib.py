@@ -11,7 +11,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnanovllm_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -39,10 +39,10 @@ PROTOTYPES = {
     "nv_attn_decode_suggest_chunk": (_i32, [_i32, _i32, _i32, _i32, _i64]),
     "nv_attn_decode_workspace_bytes_chunked": (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "nv_attn_decode_paged_chunked": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
-                                            _i32, _i64, _i32, _f32, _i64, _i64, _vp, _i64, _i32, _vp]),
+                                            _i32, _i64, _i32, _f32, _i64, _i64, _vp, _i64, _i32, _i32, _vp]),
     "nv_attn_decode_paged_fused_chunked": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                   _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _i64, _f32, _f32,
-                                                  _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp]),
+                                                  _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp]),
     "nv_attn_decode_static_scratch_bytes": (_i64, []),
     "nv_attn_decode_paged_static": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32,
                                            _i32, _i64, _i32, _f32, _i64, _i64, _vp]),

@@ -1257,7 +1257,7 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
                          int H_kv, int D, int64_t num_blocks, int block_size, float scale,
                          int64_t q_stride_t, int64_t o_stride_t, void* workspace,
                          int64_t workspace_bytes, bool library_workspace, void* stream,
-                         const FusedDecodeIn* fused = nullptr, int chunk_keys = 0) {
+                         const FusedDecodeIn* fused = nullptr, int chunk_keys = 0, int flags = 0) {
     NV_REQUIRE(B >= 0 && max_blocks > 0 && max_seqlen_k >= 0 && H_q > 0 && H_kv > 0 &&
                    num_blocks > 0 && block_size > 0,
                NV_ERR_INVALID_ARG, "nv_attn_decode_paged: bad sizes B=%d max_blocks=%d max_k=%d", B,
@@ -1344,11 +1344,13 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
         // is also the default for launches with at most 8 (sequence, kv head) pairs, the one case where it
         // measured ahead of the second launch (1 sequence x 32 k keys x 8 kv heads: 31.7 - 32.0 against 32.2 - 33.0 us).
         const int sl = tuning().decode_single_launch;
-        single = (sl == 1 || (sl < 0 && library_workspace && (int64_t)B * H_kv <= 8)) && ticket_bytes <= kTicketRegion &&
-                 !fused;   // (the fused instantiations carry no in-launch combine)
+        // ... and on a caller's workspace whose counters the caller vouches for (NV_DECODE_WS_COUNTERS_ZERO).
+        const bool counters_zero = library_workspace || (flags & NV_DECODE_WS_COUNTERS_ZERO) != 0;
+        single = (sl == 1 || (sl < 0 && counters_zero && (int64_t)B * H_kv <= 8)) && ticket_bytes <= kTicketRegion &&
+                 (!fused || plan.wgs);   // (the fused instantiations carry the in-launch combine for workgroup items only)
         if (single) {
             p.tickets = static_cast<int*>(workspace);
-            if (!library_workspace) {
+            if (!counters_zero) {
                 const hipError_t e = hipMemsetAsync(workspace, 0, (size_t)ticket_bytes, st);
                 NV_REQUIRE(e == hipSuccess, NV_ERR_LAUNCH, "nv_attn_decode_paged: hipMemsetAsync failed: %s",
                            hipGetErrorString(e));
@@ -1403,13 +1405,15 @@ static int decode_launch(const void* q, const void* k_cache, const void* v_cache
     } while (0)
 #define NV_DEC_LAUNCH_F(GG)                                                                          \
     do {                                                                                            \
-        if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);        \
+        if (wgs && single) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, true, true, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else if (wgs) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);   \
         else if (lean) hipLaunchKernelGGL((attn_decode_kernel<GG, true, 0, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
         else hipLaunchKernelGGL((attn_decode_kernel<GG, true, 1, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);           \
     } while (0)
 #define NV_DEC_LAUNCH_MF(GG)                                                                         \
     do {                                                                                            \
-        if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);            \
+        if (wgs && single) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, true, true, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
+        else if (wgs) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, true, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);   \
         else if (mfma_deep) hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 1, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p); \
         else hipLaunchKernelGGL((attn_decode_mfma_kernel<GG, true, 0, false, false, true>), dim3(grid), dim3(kDecWaves * 64), 0, st, p);               \
     } while (0)
@@ -1505,10 +1509,10 @@ extern "C" int nv_attn_decode_paged_chunked(const void* q, const void* k_cache, 
                                             int max_seqlen_k, int H_q, int H_kv, int D, int64_t num_blocks,
                                             int block_size, float scale, int64_t q_stride_t,
                                             int64_t o_stride_t, void* workspace, int64_t workspace_bytes,
-                                            int chunk_keys, void* stream) {
+                                            int chunk_keys, int flags, void* stream) {
     return nv::decode_launch(q, k_cache, v_cache, o, cu_seqlens_q, cu_seqlens_k, block_tables, B, max_blocks,
                              max_seqlen_k, H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t,
-                             workspace, workspace_bytes, false, stream, nullptr, chunk_keys);
+                             workspace, workspace_bytes, false, stream, nullptr, chunk_keys, flags);
 }
 
 extern "C" int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, const void* v, const void* q_w,
@@ -1519,7 +1523,7 @@ extern "C" int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, 
                                                   int64_t num_blocks, int block_size, int64_t max_pos, float eps,
                                                   float scale, int64_t q_stride_t, int64_t k_stride_t,
                                                   int64_t v_stride_t, int64_t o_stride_t, void* workspace,
-                                                  int64_t workspace_bytes, int chunk_keys, void* stream) {
+                                                  int64_t workspace_bytes, int chunk_keys, int flags, void* stream) {
     using namespace nv;
     NV_REQUIRE(B >= 0 && H_kv > 0 && max_pos > 0, NV_ERR_INVALID_ARG,
                "nv_attn_decode_paged_fused: bad sizes B=%d H_kv=%d max_pos=%lld", B, H_kv, (long long)max_pos);
@@ -1547,7 +1551,7 @@ extern "C" int nv_attn_decode_paged_fused_chunked(const void* q, const void* k, 
     f.eps = eps;
     return decode_launch(q, k_cache, v_cache, o, nullptr, cu_seqlens_k, block_tables, B, max_blocks, max_seqlen_k,
                          H_q, H_kv, D, num_blocks, block_size, scale, q_stride_t, o_stride_t, workspace,
-                         workspace_bytes, false, stream, &f, chunk_keys);
+                         workspace_bytes, false, stream, &f, chunk_keys, flags);
 }
 
 extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const void* v, const void* q_w, const void* k_w,
@@ -1562,7 +1566,7 @@ extern "C" int nv_attn_decode_paged_fused(const void* q, const void* k, const vo
     return nv_attn_decode_paged_fused_chunked(q, k, v, q_w, k_w, cos_sin, positions, slot_mapping, k_cache, v_cache, o,
                                               cu_seqlens_k, block_tables, B, max_blocks, max_seqlen_k, H_q, H_kv, D,
                                               num_blocks, block_size, max_pos, eps, scale, q_stride_t, k_stride_t,
-                                              v_stride_t, o_stride_t, workspace, workspace_bytes, 0, stream);
+                                              v_stride_t, o_stride_t, workspace, workspace_bytes, 0, 0, stream);
 }
 
 extern "C" int64_t nv_attn_decode_static_scratch_bytes(void) {

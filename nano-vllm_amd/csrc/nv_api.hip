@@ -32,7 +32,7 @@ extern "C" const char* nv_strerror(int code) {
     }
 }
 
-extern "C" int nv_abi_version(void) { return 6; }
+extern "C" int nv_abi_version(void) { return 7; }
 
 extern "C" int nv_set_tuning(const nv_tuning* t) {
     if (!t) {

@@ -143,14 +143,16 @@ class _DecodeGraph:
                                 max_seqlen_k_decode=width * runner.block_size, decode_chunk_keys=chunk_keys)
         set_context(self.ctx)
         # warm-up on a side stream (library initialisation must not happen inside the capture)
-        side = torch.cuda.Stream(device=dev)
+        side = runner.capture_stream()          # one side stream for all captures: they share its per-stream buffers
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             runner.model(self.input_ids, self.positions)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # captured on the stream of the warm-up: per-stream buffers of the launches (split-key workspaces, the
+        # zero-initialised one of small decode launches) exist already and are the ones the graph keeps using
+        with torch.cuda.graph(self.graph, stream=side):
             self.logits = runner.model(self.input_ids, self.positions)
 
     def replay(self, m: dict, src_rows: np.ndarray | None = None, prev_tokens: torch.Tensor | None = None) -> torch.Tensor:
@@ -211,6 +213,11 @@ class ModelRunner:
         # plan decode launches with the step's lengths (False: from the longest one alone, as a caller of the
         # reference's interface would; kept as a switch for measurements)
         self.use_length_hints = True
+
+    def capture_stream(self) -> "torch.cuda.Stream":
+        if getattr(self, "_capture_stream", None) is None:
+            self._capture_stream = torch.cuda.Stream(device=self.device)
+        return self._capture_stream
 
     # ---- KV cache -------------------------------------------------------------------------
     def block_bytes(self) -> int:

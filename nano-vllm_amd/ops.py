@@ -41,6 +41,33 @@ def _rows_ok(t: torch.Tensor, name: str) -> None:
     _need(t.stride(2) == 1 and t.stride(1) == t.shape[2], f"{name}: heads and head_dim must be contiguous")
 
 
+_small_decode_ws: dict[tuple[int, int], torch.Tensor] = {}
+_SMALL_DECODE_PAIRS = 8            # (sequence, kv head) pairs up to which a decode launch combines in-launch
+_COUNTERS_ZERO = 1                 # NV_DECODE_WS_COUNTERS_ZERO
+
+
+def _decode_workspace(device: torch.device, nbytes: int, pairs: int) -> tuple[torch.Tensor, int]:
+    """Workspace and flags of a decode launch.  Launches with at most 8 (sequence, kv head) pairs get a buffer of
+    their own per (device, stream) whose arrival counters start at zero and that nothing else ever writes (the
+    shared buffer below also holds the prefill launches' states): the library can then combine the key ranges
+    inside the launch instead of in a second kernel, and leaves the counters at zero again."""
+    if pairs > _SMALL_DECODE_PAIRS or nbytes <= 16:
+        return _workspace(device, nbytes), 0
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(device).cuda_stream)
+    ws = _small_decode_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            # zeroing a fresh buffer here would put a 16 MiB memset into the graph: such a capture keeps the merge
+            # launch (captures on a stream that has run the step before, as the engine's do, find their buffer)
+            return _workspace(device, nbytes), 0
+        if ws is not None:
+            _retired.append(ws)
+        ws = torch.zeros(max(nbytes, 16 << 20), dtype=torch.uint8, device=device)
+        _small_decode_ws[key] = ws
+    return ws, _COUNTERS_ZERO
+
+
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """Split-key scratch of the attention launches: one buffer per (device, stream), so launches on different
     streams of one device never share partial states (launches on one stream are ordered)."""
@@ -114,13 +141,13 @@ def attn_decode_paged(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
         _need(out.shape == q.shape, "out shape != q shape")
     dll = _lib.lib()
     need = dll.nv_attn_decode_workspace_bytes_chunked(B, hq, hkv, d, int(max_seqlen_k), int(chunk_keys))
-    ws = _workspace(q.device, need)
+    ws, flags = _decode_workspace(q.device, need, B * hkv)
     rc = dll.nv_attn_decode_paged_chunked(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), out.data_ptr(),
                                           cu_seqlens_q.data_ptr() if cu_seqlens_q is not None else None,
                                           cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B,
                                           block_tables.shape[1], int(max_seqlen_k), hq, hkv, d, nb, bs,
                                           float(scale), q.stride(0), out.stride(0), ws.data_ptr(), ws.numel(),
-                                          int(chunk_keys), _stream(q))
+                                          int(chunk_keys), flags, _stream(q))
     _lib.check(rc, "nv_attn_decode_paged_chunked")
     return out
 
@@ -201,7 +228,7 @@ def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.T
         _need(out.shape == q.shape, "out shape != q shape")
     dll = _lib.lib()
     need = dll.nv_attn_decode_workspace_bytes_chunked(B, hq, hkv, d, int(max_seqlen_k), int(chunk_keys))
-    ws = _workspace(q.device, need)
+    ws, flags = _decode_workspace(q.device, need, B * hkv)
     rc = dll.nv_attn_decode_paged_fused_chunked(
         q.data_ptr(), k.data_ptr(), v.data_ptr(),
         q_weight.data_ptr() if q_weight is not None else None,
@@ -209,7 +236,8 @@ def attn_decode_paged_fused(positions: torch.Tensor, q: torch.Tensor, k: torch.T
         cos_sin.data_ptr(), positions.data_ptr(), slot_mapping.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
         out.data_ptr(), cu_seqlens_k.data_ptr(), block_tables.data_ptr(), B, block_tables.shape[1],
         int(max_seqlen_k), hq, hkv, d, nb, bs, cos_sin.shape[0], float(eps), float(scale),
-        q.stride(0), k.stride(0), v.stride(0), out.stride(0), ws.data_ptr(), ws.numel(), int(chunk_keys), _stream(q))
+        q.stride(0), k.stride(0), v.stride(0), out.stride(0), ws.data_ptr(), ws.numel(), int(chunk_keys), flags,
+        _stream(q))
     _lib.check(rc, "nv_attn_decode_paged_fused_chunked")
     return out
 

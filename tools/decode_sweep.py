@@ -93,7 +93,7 @@ def main():
                             w.BS, w.MAX_POS, w.EPS, w.scale, w.q_in.stride(0), w.k_in.stride(0), w.v_in.stride(0),
                             w.o.stride(0), ws.data_ptr(), ws.numel(), stream)
                     elif args.chunk_by_call and chunk > 0:    # the host's chunk as an argument (what a runner passes)
-                        rc = dll.nv_attn_decode_paged_chunked(*args_, ws.data_ptr(), ws.numel(), chunk, stream)
+                        rc = dll.nv_attn_decode_paged_chunked(*args_, ws.data_ptr(), ws.numel(), chunk, 0, stream)
                     else:
                         rc = dll.nv_attn_decode_paged(*args_, ws.data_ptr(), ws.numel(), stream)
                     assert rc == 0, dll.nv_last_error()
