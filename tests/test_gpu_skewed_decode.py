@@ -149,3 +149,22 @@ def test_engine_plans_a_skewed_decode_step_with_the_hint():
     assert any(k[2] > 0 for k in runner._graphs)
     # a balanced batch of the same size keeps the plan's own choice
     assert runner._decode_chunk(dict(num_leading_decode=256, sum_seqlen_k_decode=256 * 640), 768) == 0
+
+
+def test_small_launches_combine_in_launch_on_the_zeroed_buffer_and_leave_it_zero(hip):
+    """Launches with at most 8 (sequence, kv head) pairs go through ops' zero-initialised buffer and combine their
+    key ranges inside the launch (NV_DECODE_WS_COUNTERS_ZERO): several launches in a row, of different sizes, meet
+    the oracle, and the arrival counters are zero again after each."""
+    from nanovllm_amd import ops
+    for i, (H_q, H_kv, ctx) in enumerate([(16, 8, [9000]), (8, 1, [3000, 70, 5000]), (32, 8, [20000]), (16, 8, [300])]):
+        bs = 256
+        nb = sum(math.ceil(c / bs) for c in ctx) + 2
+        p = make_paged_problem(70 + i, [1] * len(ctx), ctx, H_q, H_kv, bs, nb, device=DEV)
+        ref = ref_attention.paged_attention_ref(p["q"].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(), p["cu_q"].cpu(),
+                                                p["cu_k"].cpu(), p["block_tables"].cpu(), p["scale"])
+        o = hip.attn_decode_paged(p["q"], p["k_cache"], p["v_cache"], p["cu_k"], p["block_tables"], p["max_k"], p["scale"])
+        torch.cuda.synchronize()
+        assert_rows_close(o, ref, f"small launch {i}")
+        assert ops._small_decode_ws, "the small launches' buffer was not used"
+        for ws in ops._small_decode_ws.values():
+            assert int(ws[:65536].view(torch.int32).abs().sum()) == 0, "arrival counters not back at zero"
