@@ -409,6 +409,22 @@ def decode_config_records(dev, iters=40):
                     "bytes": nbytes, "ms": round(ms, 5), "achieved_GBps": round(gbps, 1), "peak": HBM_PEAK_GBPS,
                     "frac": round(gbps / HBM_PEAK_GBPS, 4)})
 
+        if B * H_kv <= 8:
+            # few (sequence, kv head) pairs: the key ranges combined inside the launch, on a workspace whose arrival
+            # counters start at zero and that nothing else writes (what nanovllm_amd.ops gives such launches)
+            wz = torch.zeros(max(1 << 16, ws.numel()), dtype=torch.uint8, device=dev)
+
+            def launch_combined(l):
+                rc = dll.nv_attn_decode_paged_chunked(q.data_ptr(), caches[l][0].data_ptr(), caches[l][1].data_ptr(),
+                                                      o.data_ptr(), cu_q.data_ptr(), cu_k.data_ptr(), bt.data_ptr(), B,
+                                                      width, ctx, H_q, H_kv, D, NB, bs, D ** -0.5, q.stride(0),
+                                                      o.stride(0), wz.data_ptr(), wz.numel(), 0, 1, stream)
+                if rc != 0:
+                    _lib.check(rc, "nv_attn_decode_paged_chunked")
+            ms_c = _time_launches(launch_combined, L, iters, dev)
+            out[-1]["ms_in_launch_combine"] = round(ms_c, 5)
+            out[-1]["frac_in_launch_combine"] = round(nbytes / (ms_c * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+
         # the decode step's whole attention block at this shape: the scatter launch (q/k-norm + rotary + KV store)
         # followed by the attention launch, against the one launch that does both (raw projections in)
         q_raw = torch.randn(B, H_q, D, device=dev).bfloat16()
