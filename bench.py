@@ -71,7 +71,7 @@ class Workload:
     H_Q, H_KV, D, HIDDEN, BS = 16, 8, 128, 1024, 256
     EPS, MAX_POS, ROPE_BASE = 1e-6, 40960, 1e6
 
-    def __init__(self, dev, layers, batch, lo, hi, seed=0, long_tail=()):
+    def __init__(self, dev, layers, batch, lo, hi, seed=0, long_tail=(), sort_rows=""):
         """`long_tail`: (count, length) pairs that replace the first sequences' lengths (tuning aid: skewed batches)."""
         from nanovllm_amd.layers.rope import build_cos_sin_cache
         self.dev, self.L, self.B = dev, layers, batch
@@ -84,6 +84,8 @@ class Workload:
         if long_tail:                    # the long ones anywhere in the batch
             order = torch.randperm(batch, generator=g).tolist()
             self.ctx = [self.ctx[j] for j in order]
+        if sort_rows:                    # tuning aid: rows by length ("desc": longest first)
+            self.ctx.sort(reverse=sort_rows == "desc")
         blocks = [math.ceil(c / self.BS) for c in self.ctx]
         self.NB = sum(blocks)
         perm = torch.randperm(self.NB, generator=g).tolist()

@@ -323,6 +323,9 @@ class ModelRunner:
         """Pipelined decode: enqueue a decode-only step without waiting for the previous step's token
         values.  Sequences whose last output token is still PENDING take it on the device from `prev`
         (the handle this method returned for the previous step).  Returns a handle for fetch_tokens()."""
+        order = self.decode_order(seqs)
+        if order is not None:                               # fetch_tokens() answers in the caller's order
+            seqs = [seqs[i] for i in order]
         m = prepare_inputs(seqs, self.block_size)
         src = np.full(len(seqs), -1, dtype=np.int64)
         if prev is not None:
@@ -345,7 +348,7 @@ class ModelRunner:
                 input_ids = torch.where(src_d >= 0, prev_tokens[src_d.clamp(min=0)], input_ids)
             logits = self.model(input_ids, positions)
         tokens = self._sample(logits, [s.sampling_params.temperature for s in seqs])
-        handle = {"rows": {s.id: i for i, s in enumerate(seqs)}, "tokens": tokens, "event": None}
+        handle = {"rows": {s.id: i for i, s in enumerate(seqs)}, "tokens": tokens, "event": None, "order": order}
         if self.device.type == "cuda":
             host = torch.empty(len(seqs), dtype=torch.int64, pin_memory=True)
             host.copy_(tokens, non_blocking=True)
@@ -360,7 +363,14 @@ class ModelRunner:
     def fetch_tokens(handle: dict) -> list[int]:
         if handle["event"] is not None:
             handle["event"].synchronize()
-        return handle["host"].tolist()
+        tokens = handle["host"].tolist()
+        order = handle.get("order")
+        if order is not None:
+            back = [0] * len(tokens)
+            for row, i in enumerate(order):
+                back[i] = tokens[row]
+            tokens = back
+        return tokens
 
     @torch.inference_mode()
     def run(self, seqs: list[Sequence]) -> list[int | None]:
@@ -368,6 +378,9 @@ class ModelRunner:
         sequence's prompt is still being chunked or its K/V is being recomputed (model_runner.py:214-240)."""
         order = None
         if self.use_graphs and all(s.num_scheduled_tokens == 1 for s in seqs):
+            order = self.decode_order(seqs)
+            if order is not None:
+                seqs = [seqs[i] for i in order]
             m = prepare_inputs(seqs, self.block_size)
             g = self._graph_for(len(seqs), m["block_tables"].shape[1], m)
             set_context(g.ctx)
@@ -389,16 +402,36 @@ class ModelRunner:
             out = back
         return out
 
+    sort_decode_rows_from = 64       # decode steps of at least this many rows go to the launch longest first
+
+    @staticmethod
+    def decode_order(seqs: list[Sequence]) -> list[int] | None:
+        """Row order of a decode-only step: longest sequence first once the step has sort_decode_rows_from rows.
+        The decode launch hands out its work items in row order and ends with its last workgroup, so the long
+        rows should not be the ones that start last (512 rows of 100 .. 2000 keys: 419 us in random order, 353
+        longest first; 256 rows of 513 .. 767 keys: no difference; fewer rows do not fill the chip and have no
+        tail to shorten).  None when the order stands."""
+        if len(seqs) < ModelRunner.sort_decode_rows_from:
+            return None
+        lens = np.fromiter((s.num_computed_tokens for s in seqs), dtype=np.int64, count=len(seqs))
+        order = np.argsort(-lens, kind="stable")
+        if np.array_equal(order, np.arange(len(seqs))):
+            return None
+        return order.tolist()
+
     @staticmethod
     def step_order(seqs: list[Sequence]) -> list[int] | None:
         """Row order of a step that holds prompt chunks: the single-token rows first (they are the decode
-        kernel's, in the scheduler's order), then the others by key count, longest first.  The attention launch
+        kernel's; in the scheduler's order, or longest first as in decode_order()), then the others by key count,
+        longest first.  The attention launch
         takes its work in row order and ends when its last workgroup does, so the longest sequences should start
         first (seven 512-token chunks over 512 .. 8192 cached keys: 212 us in scheduler order, 191 longest first).
         None when the order stands."""
         single = [i for i, s in enumerate(seqs) if s.num_scheduled_tokens == 1]
         rest = [i for i, s in enumerate(seqs) if s.num_scheduled_tokens != 1]
-        if len(rest) < 2 and (not rest or not single or single[-1] < rest[0]):
+        if len(single) >= ModelRunner.sort_decode_rows_from:
+            single.sort(key=lambda i: -seqs[i].num_computed_tokens)        # stable: ties keep the scheduler's order
+        elif len(rest) < 2 and (not rest or not single or single[-1] < rest[0]):
             return None
         rest.sort(key=lambda i: -(seqs[i].num_computed_tokens + seqs[i].num_scheduled_tokens))
         order = single + rest

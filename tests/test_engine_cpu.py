@@ -455,3 +455,32 @@ def test_step_order_puts_single_token_rows_first_and_long_prompt_chunks_ahead():
         return {index[s.id]: t for s, t in zip(batch, toks)}
     a, b = first_tokens([0, 1, 2]), first_tokens([2, 0, 1])
     assert a == b and all(t is not None for t in a.values())
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_decode_rows_go_longest_first_and_tokens_keep_their_sequences(pipelined, monkeypatch):
+    """ModelRunner.decode_order: decode-only steps of enough rows are handed to the launch longest first; the
+    synchronous loop and the pipelined one (whose handles carry the order) give every sequence the tokens it
+    gets with the scheduler's order."""
+    from nanovllm_amd.engine.model_runner import ModelRunner
+
+    def seq(computed):
+        s = Sequence(list(range(computed + 6)), SamplingParams(0.0, 4))
+        s.num_computed_tokens, s.num_scheduled_tokens, s.output_tokens = computed, 1, [7]
+        return s
+    rows = [seq(n) for n in (40, 900, 40, 12, 900)]
+    assert ModelRunner.decode_order(rows) is None                                  # below the row count
+    monkeypatch.setattr(ModelRunner, "sort_decode_rows_from", 2)
+    assert ModelRunner.decode_order(rows) == [1, 4, 0, 2, 3]                       # ties keep their order
+    assert ModelRunner.decode_order([rows[1], rows[0], rows[3]]) is None           # already longest first
+
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (9, 44, 17, 60, 30, 5)]
+    params = [SamplingParams(0.0, n) for n in (7, 5, 9, 3, 8, 6)]
+    sorted_eng, _ = _tiny_engine(16, 64, pipelined_decode=pipelined)
+    got, _ = sorted_eng.generate(prompts, params)
+    monkeypatch.setattr(ModelRunner, "sort_decode_rows_from", 1 << 30)
+    plain_eng, _ = _tiny_engine(16, 64, pipelined_decode=pipelined)
+    want, _ = plain_eng.generate(prompts, params)
+    assert [o["token_ids"] for o in got] == [o["token_ids"] for o in want]
+    assert all(len(o["token_ids"]) == p.max_tokens for o, p in zip(got, params))

@@ -33,13 +33,14 @@ def main():
     ap.add_argument("--long", default="", help="skewed batch: comma list of COUNT:LENGTH replacing the first sequences")
     ap.add_argument("--chunk-by-call", action="store_true", help="positive chunks go in as nv_attn_decode_paged_chunked's argument instead of the process-wide override")
     ap.add_argument("--hint", action="store_true", help="add a row per library with the chunk nv_attn_decode_suggest_chunk gives for the batch's lengths")
+    ap.add_argument("--sort", default="", choices=["", "desc", "asc"], help="order the batch's sequences by length")
     ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
     ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point),fused (one-launch step)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     bench.Workload.H_Q, bench.Workload.H_KV = args.hq, args.hkv
     long_tail = [tuple(int(x) for x in item.split(":")) for item in args.long.split(",") if item]
-    w = bench.Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi, long_tail=long_tail)
+    w = bench.Workload(dev, args.layers, args.batch, args.ctx_lo, args.ctx_hi, long_tail=long_tail, sort_rows=args.sort)
     libs = {"default": _lib.LIB_PATH}
     for path in sorted(glob.glob(os.path.join(ROOT, "nano-vllm_amd", "lib", "variants", "lib_*.so"))):
         libs[os.path.basename(path)[4:-3]] = path

@@ -131,6 +131,30 @@ def run_skewed_batch(model_name="qwen3_0_6b", n_short=255, short_len=512, long_l
     return s
 
 
+def run_uneven_batch(model_name="qwen3_0_6b", batch=512, lo=100, hi=2000, out_len=64, device="cuda:0", seed=0,
+                     longest_first=True):
+    """`batch` prompts of U[lo, hi] tokens decoding together: more decode work items than the chip holds at once,
+    of very different lengths.  `longest_first`: the runner hands decode rows to the launch longest first
+    (default) or in the scheduler's order."""
+    from nanovllm_amd.engine.model_runner import ModelRunner
+    if not longest_first:
+        ModelRunner.sort_decode_rows_from = 1 << 30
+    cfg, model = _build(model_name, device, seed)
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(lo, hi + 1, (batch,), generator=g).tolist()
+    blocks = sum(-(-(n + out_len) // 256) for n in lens) + 16
+    eng = LLMEngine(model, cfg, block_size=256, num_kvcache_blocks=blocks, max_num_batched_tokens=16384, device=device,
+                    eos=-1, use_graphs=True, pipelined_decode=True)
+    warm = [torch.randint(0, cfg.vocab_size, (300,), generator=g).tolist() for _ in range(8)]
+    eng.generate(warm, SamplingParams(0.0, 3))
+    prompts = [torch.randint(0, cfg.vocab_size, (n,), generator=g).tolist() for n in lens]
+    torch.cuda.synchronize()
+    outs, m = eng.generate(prompts, SamplingParams(0.0, out_len))
+    s = m.summary()
+    s.update(model=model_name, batch=batch, prompt_lens=f"U[{lo},{hi}]", out_len=out_len, longest_first=longest_first)
+    return s
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="qwen3_0_6b")
@@ -141,8 +165,9 @@ if __name__ == "__main__":
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--no-fuse-gemms", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="synchronous decode loop (token values read every step)")
-    ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode", "skewed_batch"])
+    ap.add_argument("--scenario", default="batch", choices=["batch", "long_prompt", "long_context_decode", "skewed_batch", "uneven_batch"])
     ap.add_argument("--no-length-hints", action="store_true", help="skewed_batch: plan decode launches from the longest length alone")
+    ap.add_argument("--scheduler-order", action="store_true", help="uneven_batch: decode rows stay in the scheduler's order")
     ap.add_argument("--ctx", type=int, default=32768)
     ap.add_argument("--prefill-kernel", type=int, default=-1, choices=[-1, 0, 1],
                     help="force the compiler-scheduled (0) or the hand-scheduled (1) prefill kernel; -1 = heuristic")
@@ -155,6 +180,10 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.scenario == "skewed_batch":
         print(json.dumps(run_skewed_batch(a.model, hints=not a.no_length_hints)))
+        sys.exit(0)
+    if a.scenario == "uneven_batch":
+        print(json.dumps(run_uneven_batch(a.model, a.batch if a.batch != 256 else 512, out_len=a.out_len if a.out_len != 256 else 64,
+                                          longest_first=not a.scheduler_order)))
         sys.exit(0)
     if a.scenario == "long_context_decode":
         print(json.dumps(run_long_context_decode(a.model if a.model != "qwen3_0_6b" else "llama31_8b",
