@@ -1213,6 +1213,14 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
     const long long bh = (long long)B * H_kv;
     const long long target = d.mfma ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES;
     const long long mean = (sum_seqlen_k + B - 1) / B;
+    // Only for real skew.  The longest sequence under 3 x the mean: the plan's own split is as good or better
+    // (sequences of 100 .. 2000 keys, rows longest first, hinted against not: 64 sequences 66 against 60 us, 384:
+    // 288 / 281, 512: 378 / 349, 1024: 732 / 660; 32 / 8 heads, 256: 225 / 208).  And the longest sequence must be
+    // on the launch's critical path: one workgroup streams its keys about as fast as the chip's 256 compute units
+    // stream 256 workgroups' keys, so a sequence with less than 0.3 of sum x H_kv / 256 keys ends well before the
+    // launch does, wherever it starts.
+    if (max_seqlen_k < 3 * mean) return 0;
+    if ((long long)max_seqlen_k * 256 * 10 < 3 * sum_seqlen_k * H_kv) return 0;
     if (bh < target) {
         // Few pairs: the plan cuts every sequence into max / chunk ranges so that the launch has about `target`
         // waves -- which it only reaches when the sequences are equally long (the short ones of an uneven batch
@@ -1224,9 +1232,8 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
         if (chunk < least) chunk = least;
         return chunk * 4 <= (long long)d.chunk * 3 ? (int)chunk : 0;      // only when it is a real change
     }
-    // balanced enough: the longest sequence within 1.4 x the mean, or less than 512 keys beyond it (a split
-    // costs a merge launch and partial states: about 6 us)
-    if ((long long)max_seqlen_k * 5 < mean * 7 || max_seqlen_k - mean < 512) return 0;
+    // less than 512 keys beyond the mean: a split costs a merge launch and partial states, about 6 us
+    if (max_seqlen_k - mean < 512) return 0;
     // pieces of about three quarters of a mean sequence; twice that for the MFMA-score kernels, whose partial
     // states hold 4 - 8 query heads per kv head (64 / 8 heads, one 8192-key sequence among 256 of ~640 keys:
     // 172 us with 512-key pieces, 155 with 1024, 192 planned from the longest length alone)
