@@ -505,6 +505,37 @@ def decode_skew_records(dev, iters=20):
     return out
 
 
+def decode_row_order_records(dev, iters=10):
+    """The decode launch on batches with more work items than the chip holds at once and lengths spread over
+    100 .. 2000 keys: rows in random order against longest first (the order ModelRunner.decode_order gives the
+    launch; the kernel and its plan are the same)."""
+    from nanovllm_amd import _lib
+    dll = _lib.lib()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    out = []
+    for batch in (128, 512):
+        rec = {"workload": f"{batch} sequences of 100..2000 keys, H {Workload.H_Q}/{Workload.H_KV}, block {Workload.BS}"}
+        for key, order in (("ms_random_order", ""), ("ms_longest_first", "desc")):
+            w = Workload(dev, 2, batch, 100, 2000, sort_rows=order)
+            ws = torch.empty(max(16, dll.nv_attn_decode_workspace_bytes(w.B, w.H_Q, w.H_KV, w.D, w.max_k)),
+                             dtype=torch.uint8, device=dev)
+
+            def launch(l):
+                rc = dll.nv_attn_decode_paged(w.q_rot.data_ptr(), w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(),
+                                              w.o.data_ptr(), w.cu_q.data_ptr(), w.cu_k.data_ptr(), w.block_tables.data_ptr(),
+                                              w.B, w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB, w.BS, w.scale,
+                                              w.q_rot.stride(0), w.o.stride(0), ws.data_ptr(), ws.numel(), stream)
+                if rc != 0:
+                    _lib.check(rc, "nv_attn_decode_paged")
+            rec[key] = round(_time_launches(launch, w.L, iters, dev), 5)
+            rec["bytes"] = w.attn_bytes_per_launch()
+            del w, ws
+            torch.cuda.empty_cache()
+        rec["GBps_longest_first"] = round(rec["bytes"] / (rec["ms_longest_first"] * 1e-3) / 1e9, 1)
+        out.append(rec)
+    return out
+
+
 def cpu_baseline_other(seconds_each: float = 3.0):
     """The oracle's remaining kernels on the host cores, bounded samples: KV scatter, residual-add RMSNorm,
     rotary embedding (GB/s of the same algorithmic bytes as the GPU kernels) and prefill attention (TFLOP/s)."""
@@ -830,7 +861,7 @@ def main():
     tp = None if args.no_tp else guarded(tp_bench, args, dev, rank, world, dist)
     dp5 = None if args.no_tp else guarded(dp_config5_bench, args, dev, rank, world, dist)
 
-    extra_prefill = extra_cfg = extra_skew = ceiling = None
+    extra_prefill = extra_cfg = extra_skew = extra_order = ceiling = None
     if rank == 0 and not args.no_prefill:
         ceiling = guarded(mfma_ceiling_record, dev)
         ceil_tf = ceiling.get("achieved_tflops") if isinstance(ceiling, dict) else None
@@ -838,6 +869,7 @@ def main():
     if rank == 0 and not args.no_configs:
         extra_cfg = guarded(decode_config_records, dev)
         extra_skew = guarded(decode_skew_records, dev)
+        extra_order = guarded(decode_row_order_records, dev)
 
     if rank == 0:
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be
@@ -899,6 +931,8 @@ def main():
             out["decode_by_config"] = extra_cfg
         if extra_skew is not None:
             out["decode_skewed_batches"] = extra_skew
+        if extra_order is not None:
+            out["decode_row_order"] = extra_order
         if tp is not None:
             out["head_sharded"] = tp
         if dp5 is not None:
