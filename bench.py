@@ -84,7 +84,12 @@ class Workload:
         if long_tail:                    # the long ones anywhere in the batch
             order = torch.randperm(batch, generator=g).tolist()
             self.ctx = [self.ctx[j] for j in order]
-        if sort_rows:                    # tuning aid: rows by length ("desc": longest first)
+        if sort_rows.startswith("snake"):        # tuning aid: longest first, every other run of N rows reversed ("snake32")
+            period = int(sort_rows[5:])
+            self.ctx.sort(reverse=True)
+            for r in range(1, -(-batch // period), 2):
+                self.ctx[r * period:(r + 1) * period] = self.ctx[r * period:(r + 1) * period][::-1]
+        elif sort_rows:                  # tuning aid: rows by length ("desc": longest first)
             self.ctx.sort(reverse=sort_rows == "desc")
         blocks = [math.ceil(c / self.BS) for c in self.ctx]
         self.NB = sum(blocks)

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--long", default="", help="skewed batch: comma list of COUNT:LENGTH replacing the first sequences")
     ap.add_argument("--chunk-by-call", action="store_true", help="positive chunks go in as nv_attn_decode_paged_chunked's argument instead of the process-wide override")
     ap.add_argument("--hint", action="store_true", help="add a row per library with the chunk nv_attn_decode_suggest_chunk gives for the batch's lengths")
-    ap.add_argument("--sort", default="", choices=["", "desc", "asc"], help="order the batch's sequences by length")
+    ap.add_argument("--sort", default="", help="order the batch's sequences by length: desc, asc, or snakeN (longest first, every other run of N rows reversed)")
     ap.add_argument("--no-cu-q", action="store_true", help="pass no cu_seqlens_q (token b is sequence b's)")
     ap.add_argument("--modes", default="auto", help="comma list of auto,valu,mfma0,mfma1 (G >= 4 kernel choice),wgs0,wgs1 (work item = wave / workgroup),single0,single1 (merge launch / last-arriver merge),static (allocation-free entry point),fused (one-launch step)")
     args = ap.parse_args()
