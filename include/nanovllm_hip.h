@@ -112,9 +112,11 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  * alone it cannot tell 256 sequences of 2048 keys (no cut wanted) from 255 of 640 keys and one of 8192 (whose
  * few waves end the launch long after the others unless its keys are spread over many work items).
  *   nv_attn_decode_suggest_chunk: keys per work item for a batch with this sum of lengths, or 0 when the
- *     plan's own choice stands: the longest sequence under 3 x the mean length, or too short to be the launch's
- *     critical path (under 0.3 of sum x H_kv / 256 keys).  A batch without such skew gains more from handing
- *     its rows over longest first: a launch takes its work in row order and ends with its last workgroup.
+ *     plan's own choice stands: balanced batches (longest sequence within 1.4 x the mean length, or under 512
+ *     keys beyond it; within 2.5 x for launches with few (sequence, kv head) pairs), and launches with more
+ *     work items than are resident at once unless one sequence alone outlasts the rest (from about half of
+ *     sum x H_kv / 256 keys on).  Such launches gain from rows handed over longest first instead: a launch
+ *     takes its work in row order and ends with its last workgroup.
  *   nv_attn_decode_paged_chunked / nv_attn_decode_paged_fused_chunked: the entry points above with that value
  *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 256 ranges per sequence)
  *     and flags (0, or NV_DECODE_WS_COUNTERS_ZERO below).

@@ -1213,15 +1213,10 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
     const long long bh = (long long)B * H_kv;
     const long long target = d.mfma ? NV_DEC_TARGET_WAVES / 2 : NV_DEC_TARGET_WAVES;
     const long long mean = (sum_seqlen_k + B - 1) / B;
-    // Only for real skew.  The longest sequence under 3 x the mean: the plan's own split is as good or better
-    // (sequences of 100 .. 2000 keys, rows longest first, hinted against not: 64 sequences 66 against 60 us, 384:
-    // 288 / 281, 512: 378 / 349, 1024: 732 / 660; 32 / 8 heads, 256: 225 / 208).  And the longest sequence must be
-    // on the launch's critical path: one workgroup streams its keys about as fast as the chip's 256 compute units
-    // stream 256 workgroups' keys, so a sequence with less than 0.3 of sum x H_kv / 256 keys ends well before the
-    // launch does, wherever it starts.
-    if (max_seqlen_k < 3 * mean) return 0;
-    if ((long long)max_seqlen_k * 256 * 10 < 3 * sum_seqlen_k * H_kv) return 0;
     if (bh < target) {
+        // (64 sequences, rows longest first, hinted against not: lengths spread over 100 .. 2000 keys, 1.9 x the
+        // mean, 66 against 60 us; 513 .. 767 keys and one of 1500, 2.3 x: 44 / 43; one of 2000, 3.1 x: 44 / 51)
+        if ((long long)max_seqlen_k * 2 < mean * 5) return 0;
         // Few pairs: the plan cuts every sequence into max / chunk ranges so that the launch has about `target`
         // waves -- which it only reaches when the sequences are equally long (the short ones of an uneven batch
         // have one range each).  With the sum known: as many keys per work item as make the launch full.
@@ -1232,8 +1227,20 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
         if (chunk < least) chunk = least;
         return chunk * 4 <= (long long)d.chunk * 3 ? (int)chunk : 0;      // only when it is a real change
     }
-    // less than 512 keys beyond the mean: a split costs a merge launch and partial states, about 6 us
-    if (max_seqlen_k - mean < 512) return 0;
+    // Many more pairs than the target: a work item is one wave, every wave gets an equal share of the chip while
+    // the others run and streams about 9 GB/s (18 keys per us) once it is alone, so a long sequence -- at most
+    // 2048 keys per wave -- extends the launch by what it has left when the others are done.  Cutting everything
+    // into pieces costs 3 - 8 % of the whole launch (partial states, merge launch, empty work items), which
+    // grows with the launch while the extension does not: only when the longest sequence is at least half of
+    // sum x H_kv / 256 keys.  Rows longest first, hinted against not: 512 sequences of 100 .. 2000 keys 378 / 349
+    // us, with one of 6000 among them (0.36) 393 / 357, one of 10000 (0.59) 397 / 390; 512 of 513 .. 767 keys
+    // and one of 6000 (0.58) 243 / 245, one of 8192 (0.78) 260 / 286; 32 / 8 heads, 256 of 100 .. 2000 keys
+    // 225 / 208, 256 of 513 .. 767 and one of 3000 (0.57) 160 / 183.
+    if (bh * 4 > target * 5 && (long long)max_seqlen_k * 256 * 2 < sum_seqlen_k * H_kv) return 0;
+    // A launch that is resident at once ends with its longest sequence (256 sequences of 513 .. 767 keys and
+    // one of 1500: 155 us, 133 with 512-key pieces).  Balanced enough: the longest sequence within 1.4 x the
+    // mean, or less than 512 keys beyond it (a split costs a merge launch and partial states: about 6 us)
+    if ((long long)max_seqlen_k * 5 < mean * 7 || max_seqlen_k - mean < 512) return 0;
     // pieces of about three quarters of a mean sequence; twice that for the MFMA-score kernels, whose partial
     // states hold 4 - 8 query heads per kv head (64 / 8 heads, one 8192-key sequence among 256 of ~640 keys:
     // 172 us with 512-key pieces, 155 with 1024, 192 planned from the longest length alone)

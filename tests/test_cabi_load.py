@@ -168,8 +168,12 @@ def test_decode_chunk_suggestion_known_answers():
     assert f(256, 16, 8, 767, 256 * 640) == 0                      # the benchmark batch: longest = 1.2 x mean
     assert f(256, 16, 8, 2048, 256 * 2048) == 0                    # uniform long sequences: no cut wanted
     assert f(256, 16, 8, 1023, 256 * 640) == 0                     # 1.6 x the mean but only 383 keys beyond it
-    assert f(512, 16, 8, 2000, 512 * 1050) == 0                    # lengths spread evenly over 100 .. 2000: 1.9 x the mean
-    assert f(64, 16, 8, 2000, 64 * 1050) == 0                      # the same with few pairs
+    assert f(512, 16, 8, 2000, 512 * 1050) == 0                    # twice the resident work items, no sequence outlasts the rest
+    assert f(512, 16, 8, 6000, 511 * 1050 + 6000) == 0             # ... nor does one of 6000 keys among them
+    assert f(64, 16, 8, 2000, 64 * 1050) == 0                      # few pairs, 1.9 x the mean
+    assert f(64, 16, 8, 1500, 63 * 640 + 1500) == 0                # few pairs, 2.3 x the mean
+    assert f(64, 16, 8, 3000, 63 * 640 + 3000) > 0                 # few pairs, 4.4 x the mean
+    assert f(256, 16, 8, 1500, 255 * 640 + 1500) == 512            # resident at once: ends with its longest sequence
     assert f(1024, 16, 8, 4096, 1023 * 640 + 4096) == 0            # 6 x the mean, but 1/5 of a compute unit's share
     assert f(512, 16, 8, 8192, 511 * 640 + 8192) == 512            # 12 x the mean and most of a compute unit's share
     # few (sequence, kv head) pairs: the plan cuts every sequence max / chunk ways to fill the launch, which only
