@@ -116,7 +116,9 @@ NV_API int nv_attn_decode_paged(const void* q, const void* k_cache, const void* 
  *     keys beyond it; within 2.5 x for launches with few (sequence, kv head) pairs), and launches with more
  *     work items than are resident at once unless one sequence alone outlasts the rest (from about half of
  *     sum x H_kv / 256 keys on).  Such launches gain from rows handed over longest first instead: a launch
- *     takes its work in row order and ends with its last workgroup.
+ *     takes its work in row order and ends with its last workgroup.  When their lengths are spread out (longest
+ *     from 1.7 x the mean and 1024 keys on) the answer is 2048, the plan's own cap: it cuts nothing there, and
+ *     any chunk_keys > 0 tells the plan that the lengths are uneven, for which it takes the prefetching kernel.
  *   nv_attn_decode_paged_chunked / nv_attn_decode_paged_fused_chunked: the entry points above with that value
  *     (chunk_keys; 0 = the plan's choice; rounded up to a multiple of 64 keys, at most 256 ranges per sequence)
  *     and flags (0, or NV_DECODE_WS_COUNTERS_ZERO below).

@@ -1178,7 +1178,12 @@ static DecodePlan plan_decode(int B, int H_kv, int max_k, int G, int chunk_keys 
     // and waves are scarce; with many resident waves (or G = 8, where registers are the
     // limit) thread-level parallelism already covers it and the leaner kernel is faster.
     // (the lean kernel for split launches of many pairs as well measured 4 - 15 % slower on skewed batches)
-    d.lean = G >= 8 || (d.nsplit == 1 && bh >= NV_DEC_TARGET_WAVES);
+    // A caller's chunk says that the lengths are uneven: then the waves of the long sequences run on after the
+    // short ones' are gone, with less and less parallelism to hide latency behind, and the prefetch pays (rows
+    // longest first, 16 / 8 heads, lengths spread over 100 .. 2000 keys, without / with prefetch: 256 sequences
+    // 205.7 / 194.6 us, 512: 351.5 / 341.1, 1024: 659.7 / 649.6; equal lengths the other way round: 256 x 1024
+    // keys 165.7 / 171.0, 256 x 2048: 325.0 / 328.8).
+    d.lean = G >= 8 || (d.nsplit == 1 && bh >= NV_DEC_TARGET_WAVES && chunk_keys <= 0);
     // one tile of prefetch measured faster than none on every G >= 4 shape tried
     d.mfma_deep = tn.decode_mfma_depth >= 0 ? tn.decode_mfma_depth == 1 : true;
     return d;
@@ -1236,7 +1241,11 @@ extern "C" int nv_attn_decode_suggest_chunk(int B, int H_q, int H_kv, int max_se
     // us, with one of 6000 among them (0.36) 393 / 357, one of 10000 (0.59) 397 / 390; 512 of 513 .. 767 keys
     // and one of 6000 (0.58) 243 / 245, one of 8192 (0.78) 260 / 286; 32 / 8 heads, 256 of 100 .. 2000 keys
     // 225 / 208, 256 of 513 .. 767 and one of 3000 (0.57) 160 / 183.
-    if (bh * 4 > target * 5 && (long long)max_seqlen_k * 256 * 2 < sum_seqlen_k * H_kv) return 0;
+    // What such a launch can still use is the prefetch that the plan leaves out for many equal sequences: when
+    // the lengths are spread out (longest from 1.7 x the mean and 1024 keys on) the answer is the plan's own cap
+    // of 2048 keys, which cuts nothing there and tells the plan that the lengths are uneven.
+    if (bh * 4 > target * 5 && (long long)max_seqlen_k * 256 * 2 < sum_seqlen_k * H_kv)
+        return (!d.mfma && d.nsplit == 1 && max_seqlen_k > 1024 && (long long)max_seqlen_k * 10 >= mean * 17) ? 2048 : 0;
     // A launch that is resident at once ends with its longest sequence (256 sequences of 513 .. 767 keys and
     // one of 1500: 155 us, 133 with 512-key pieces).  Balanced enough: the longest sequence within 1.4 x the
     // mean, or less than 512 keys beyond it (a split costs a merge launch and partial states: about 6 us)

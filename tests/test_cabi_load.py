@@ -168,7 +168,11 @@ def test_decode_chunk_suggestion_known_answers():
     assert f(256, 16, 8, 767, 256 * 640) == 0                      # the benchmark batch: longest = 1.2 x mean
     assert f(256, 16, 8, 2048, 256 * 2048) == 0                    # uniform long sequences: no cut wanted
     assert f(256, 16, 8, 1023, 256 * 640) == 0                     # 1.6 x the mean but only 383 keys beyond it
-    assert f(512, 16, 8, 2000, 512 * 1050) == 0                    # twice the resident work items, no sequence outlasts the rest
+    # twice the resident work items, no sequence outlasts the rest: nothing to cut; lengths that spread out get the
+    # plan's own cap back, which cuts nothing and selects the prefetching kernel
+    assert f(512, 16, 8, 2000, 512 * 1050) == 2048
+    assert f(512, 16, 8, 767, 512 * 640) == 0 and f(512, 16, 8, 2000, 512 * 1900) == 0
+    assert f(512, 32, 8, 2000, 512 * 1050) == 0                    # the MFMA-score kernels always prefetch
     assert f(512, 16, 8, 6000, 511 * 1050 + 6000) == 0             # ... nor does one of 6000 keys among them
     assert f(64, 16, 8, 2000, 64 * 1050) == 0                      # few pairs, 1.9 x the mean
     assert f(64, 16, 8, 1500, 63 * 640 + 1500) == 0                # few pairs, 2.3 x the mean

@@ -94,6 +94,29 @@ def test_suggestion_for_a_skewed_batch_and_its_launch(hip):
         assert_rows_close(o[b:b + 1], ref, f"sequence {b} ({ctx[b]} keys)")
 
 
+def test_spread_out_large_batch_gets_the_unsplit_prefetching_launch(hip):
+    """384 sequences of 100 .. 2000 keys (more pairs than are resident at once, no sequence that outlasts the
+    rest): the suggestion is the plan's cap of 2048 keys, which cuts nothing; the launch meets the oracle on sampled
+    rows and the unhinted launch to fp32 summation order."""
+    g = torch.Generator().manual_seed(9)
+    ctx = sorted(torch.randint(100, 2001, (384,), generator=g).tolist(), reverse=True)
+    H_q, H_kv, bs = 16, 8, 256
+    assert hip.decode_suggest_chunk(len(ctx), H_q, H_kv, max(ctx), sum(ctx)) == 2048
+    nb = sum(math.ceil(c / bs) for c in ctx) + 2
+    p = make_paged_problem(4, [1] * len(ctx), ctx, H_q, H_kv, bs, nb, device=DEV)
+    plain = hip.attn_decode_paged(p["q"], p["k_cache"], p["v_cache"], p["cu_k"], p["block_tables"], p["max_k"], p["scale"])
+    o = hip.attn_decode_paged(p["q"], p["k_cache"], p["v_cache"], p["cu_k"], p["block_tables"], p["max_k"], p["scale"],
+                              chunk_keys=2048)
+    torch.cuda.synchronize()
+    assert (o.float() - plain.float()).abs().max().item() <= 2e-2
+    bt = p["block_tables"].cpu()
+    for b in (0, 1, 77, 200, 383):
+        ref = ref_attention.paged_attention_ref(p["q"][b:b + 1].cpu(), p["k_cache"].cpu(), p["v_cache"].cpu(),
+                                                torch.tensor([0, 1], dtype=torch.int32),
+                                                torch.tensor([0, ctx[b]], dtype=torch.int32), bt[b:b + 1], p["scale"])
+        assert_rows_close(o[b:b + 1], ref, f"sequence {b} ({ctx[b]} keys)")
+
+
 def test_engine_plans_a_skewed_decode_step_with_the_hint():
     """The runner knows every length: on a skewed decode step its context carries the suggested chunk, the step
     captured as a graph is keyed by it, and graph replay and eager step give the same logits."""

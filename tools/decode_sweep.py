@@ -86,13 +86,16 @@ def main():
                     if mode == "static":       # the allocation-free entry point (in-launch combine by default)
                         rc = dll.nv_attn_decode_paged_static(*args_, stream)
                     elif mode == "fused":      # the one-launch step: raw projections in, token stored by the launch
-                        rc = dll.nv_attn_decode_paged_fused(
-                            w.q_in.data_ptr(), w.k_in.data_ptr(), w.v_in.data_ptr(), w.q_w.data_ptr(), w.k_w.data_ptr(),
-                            w.cos_sin.data_ptr(), w.positions.data_ptr(), w.slots.data_ptr(),
-                            w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(), w.o.data_ptr(), w.cu_k.data_ptr(),
-                            w.block_tables.data_ptr(), w.B, w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB,
-                            w.BS, w.MAX_POS, w.EPS, w.scale, w.q_in.stride(0), w.k_in.stride(0), w.v_in.stride(0),
-                            w.o.stride(0), ws.data_ptr(), ws.numel(), stream)
+                        fargs = (w.q_in.data_ptr(), w.k_in.data_ptr(), w.v_in.data_ptr(), w.q_w.data_ptr(), w.k_w.data_ptr(),
+                                 w.cos_sin.data_ptr(), w.positions.data_ptr(), w.slots.data_ptr(),
+                                 w.kv_cache[0, l].data_ptr(), w.kv_cache[1, l].data_ptr(), w.o.data_ptr(), w.cu_k.data_ptr(),
+                                 w.block_tables.data_ptr(), w.B, w.block_tables.shape[1], w.max_k, w.H_Q, w.H_KV, w.D, w.NB,
+                                 w.BS, w.MAX_POS, w.EPS, w.scale, w.q_in.stride(0), w.k_in.stride(0), w.v_in.stride(0),
+                                 w.o.stride(0), ws.data_ptr(), ws.numel())
+                        if args.chunk_by_call and chunk > 0:
+                            rc = dll.nv_attn_decode_paged_fused_chunked(*fargs, chunk, 0, stream)
+                        else:
+                            rc = dll.nv_attn_decode_paged_fused(*fargs, stream)
                     elif args.chunk_by_call and chunk > 0:    # the host's chunk as an argument (what a runner passes)
                         rc = dll.nv_attn_decode_paged_chunked(*args_, ws.data_ptr(), ws.numel(), chunk, 0, stream)
                     else:
