@@ -117,6 +117,25 @@ def test_spread_out_large_batch_gets_the_unsplit_prefetching_launch(hip):
         assert_rows_close(o[b:b + 1], ref, f"sequence {b} ({ctx[b]} keys)")
 
 
+def test_spread_out_large_batch_one_launch_step_equals_the_two_launches(hip):
+    """The same kind of batch through the one-launch step with the suggested 2048 keys (unsplit, prefetching
+    instantiation): every cache byte equal to scatter-then-attention's, outputs equal up to fp32 contraction."""
+    g = torch.Generator().manual_seed(10)
+    ctx = sorted(torch.randint(100, 2001, (384,), generator=g).tolist(), reverse=True)
+    H_q, H_kv = 16, 8
+    p, q, k, v, q_w, k_w, cos_sin, pos, slots = _step(22, ctx, H_q, H_kv, 256, True)
+    chunk = hip.decode_suggest_chunk(len(ctx), H_q, H_kv, p["max_k"], sum(ctx))
+    assert chunk == 2048
+    kc1, vc1 = p["k_cache"].clone(), p["v_cache"].clone()
+    q_rot, _ = hip.qknorm_rope_store(pos, q, k, v, q_w, k_w, cos_sin, 1e-6, slots, kc1, vc1, want_k=False)
+    o1 = hip.attn_decode_paged(q_rot, kc1, vc1, p["cu_k"], p["block_tables"], p["max_k"], p["scale"], chunk_keys=chunk)
+    kc2, vc2 = p["k_cache"].clone(), p["v_cache"].clone()
+    o2 = hip.attn_decode_paged_fused(pos, q, k, v, q_w, k_w, cos_sin, 1e-6, slots, kc2, vc2, p["cu_k"],
+                                     p["block_tables"], p["max_k"], p["scale"], chunk_keys=chunk)
+    torch.cuda.synchronize()
+    _assert_same((o1, kc1, vc1), (o2, kc2, vc2), "384 spread-out sequences, 2048 keys per work item")
+
+
 def test_engine_plans_a_skewed_decode_step_with_the_hint():
     """The runner knows every length: on a skewed decode step its context carries the suggested chunk, the step
     captured as a graph is keyed by it, and graph replay and eager step give the same logits."""
